@@ -1,0 +1,151 @@
+/* tangency_posterior.h - C-ABI of libtangency.so: the MI355X (gfx950) implementation of the
+ * rolling-window Bayesian tangency-portfolio posterior.
+ *
+ * The reference (vilnik/incorporating-different-sources) has no FFI: its boundary is the Python
+ * module surface of src/portfolio_calculations.py.  The entry points below are what that module's
+ * hot path binds through ctypes in this build (incorporating_different_sources_amd/_native.py);
+ * each cites the reference interface it replaces as ref:LINE of src/portfolio_calculations.py.
+ *
+ * One "window" = one rebalancing date.  For every window w the library computes, in fp64,
+ *
+ *   X_w  (n_r x k)  rows of the daily excess-log-return panel            ref:31-62, 136-161
+ *   T = X'X, t = X'1                                                     ref:163-245
+ *   Y_w  (m x k)    rows of the intraday log-return panel                ref:310-314
+ *   S0 = n0 * m/(m-1) * (Y-Ybar)'(Y-Ybar)                                ref:317-318, 333
+ *   c  = 2 n0 / (a + sqrt(a^2 + 4 n0 w0'S0 w0)),  a = n0 + k + 2         ref:415-418
+ *   S1 = S0 + T ;  w1 = S1^-1 (c S0 w0 + t) ;  n1 = n0 + N               ref:358, 485-489, 282
+ *   weights = (n1 + k + 2) w1 / (n1 - w1'S1 w1) / gamma                  ref:572-575, 836
+ * or, for TP_STRATEGY_JEFFREYS,
+ *   weights = (T - t t'/N)^-1 t / gamma                                  ref:600-606, 849
+ *
+ * Everything is plain C: caller-allocated buffers, int return codes, no exceptions.  All arrays are
+ * row-major with the asset index contiguous.  A handle owns one GPU, one HIP stream and (optionally)
+ * one RCCL communicator; calls on one handle must be serialised by the caller.
+ * There is NO CPU fallback: tp_create fails with TP_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef TANGENCY_POSTERIOR_H
+#define TANGENCY_POSTERIOR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* return codes */
+#define TP_OK 0
+#define TP_ERR_INVALID (-1)     /* bad argument (the message is in tp_last_error) */
+#define TP_ERR_NO_DEVICE (-2)   /* no usable HIP device */
+#define TP_ERR_HIP (-3)         /* a HIP runtime call failed */
+#define TP_ERR_UNSUPPORTED (-4) /* shape outside what the kernels cover (see tp_max_assets) */
+#define TP_ERR_RCCL (-5)        /* an RCCL call failed */
+
+/* weighting strategies on the path (ref:1012-1034 dispatch) */
+#define TP_STRATEGY_CONJUGATE 0 /* calculate_conjugate_hf_mcm_portfolio, ref:819-836 */
+#define TP_STRATEGY_JEFFREYS 1  /* calculate_jeffreys_portfolio,         ref:838-849 */
+
+/* per-window status written to status[w] */
+#define TP_STATUS_OK 0
+#define TP_STATUS_NOT_PD 1    /* non-positive pivot: S1 (or J) is not positive definite (rank-deficient
+                                 window; the reference returns finite garbage) */
+#define TP_STATUS_NONFINITE 2 /* NaN/Inf in the weights (ref:492-494 raises ValueError) */
+#define TP_STATUS_BAD_DENOM 3 /* n1 - w1'S1 w1 <= 0 (ref:573 has no guard, Appendix B-Q9) */
+
+#define TP_AUX_STRIDE 8 /* doubles per window in `aux`: n0, n1, c, q0, q1, n1-q1, 0, 0 */
+
+typedef struct tp_handle_s* tp_handle_t;
+typedef struct tp_batch_s* tp_batch_t;
+
+/* The reference's portfolio_spec dict (src/portfolio_specs.py:80-90) reduced to what the path reads. */
+typedef struct tp_params {
+    int32_t k;        /* portfolio_spec["size"]            (ref:415, 572) */
+    int32_t N;        /* portfolio_spec["rolling_window"]  (ref:265, 282, 600) */
+    int32_t n_r;      /* max rows of excess returns per window (= N-1 without NaN drops, ref:60) */
+    int32_t m;        /* max intraday returns per window (conjugate only; ref:314) */
+    int32_t strategy; /* TP_STRATEGY_* */
+    int32_t reserved;
+    double gamma;     /* portfolio_spec["risk_aversion"]   (ref:836, 849) */
+} tp_params_t;
+
+/* Host-side description of W windows (all pointers are HOST pointers; optional ones may be NULL).
+ * Window w reads
+ *   daily rows   row_idx ? row_idx[w*n_r + r] : start[w] + r          for r < (n_rows ? n_rows[w] : n_r)
+ *   asset column col_idx ? col_idx[w*k + j]   : j                      for j < k
+ *   x[r][j] = panel[row*panel_ld + col] - (rf_adj ? rf_adj[w*n_r + r] : 0)     (ref:57)
+ *   intraday rows hf_row_idx ? hf_row_idx[w*m + r] : hf_start[w] + r   for r < (hf_count ? hf_count[w] : m)
+ */
+typedef struct tp_inputs {
+    const double* panel;       /* [panel_rows x panel_ld] daily log-return panel */
+    int64_t panel_rows;
+    int32_t panel_ld;
+    int32_t hf_ld;
+    const int64_t* start;      /* [W] first panel row of each window (contiguous mode) */
+    const int32_t* row_idx;    /* optional [W x n_r] explicit panel rows (overrides start) */
+    const int32_t* n_rows;     /* optional [W] rows actually used (<= n_r) */
+    const int32_t* col_idx;    /* optional [W x k] panel columns of the k selected assets */
+    const double* rf_adj;      /* optional [W x n_r] per-row risk-free adjustment, ref:48-57 */
+    const double* hf_panel;    /* [hf_rows x hf_ld] intraday log-return panel (conjugate) */
+    int64_t hf_rows;
+    const int64_t* hf_start;   /* [W] */
+    const int32_t* hf_row_idx; /* optional [W x m] */
+    const int32_t* hf_count;   /* optional [W] intraday returns actually used (<= m, >= 2) */
+    const double* w0;          /* [W x k] prior weights, ref:361-380 */
+    const double* n0;          /* [W] prior strength, ref:247-267 */
+} tp_inputs_t;
+
+const char* tp_version(void);
+/* largest portfolio_spec["size"] the built kernels cover */
+int tp_max_assets(void);
+
+/* Contexts.  tp_create binds device `device_id`, creates a stream and timing events.
+ * Replaces: nothing in the reference (it has no device); corresponds to process start-up. */
+int tp_create(int device_id, tp_handle_t* out);
+int tp_destroy(tp_handle_t h);
+const char* tp_last_error(tp_handle_t h); /* h may be NULL: last error of a failed tp_create */
+int tp_device_info(tp_handle_t h, char* name, int name_len, int* compute_units, int* clock_mhz,
+                   int64_t* hbm_bytes);
+
+/* A batch is W windows resident in HBM: inputs uploaded once, run any number of times.
+ * Replaces the per-date loop body of Portfolio.update_portfolio -> calculate_portfolio_weights
+ * (ref:1184 -> ref:941) for all rebalancing dates of a backtest at once. */
+int tp_batch_create(tp_handle_t h, const tp_params_t* p, int64_t W, tp_batch_t* out);
+int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in);   /* H2D, synchronous */
+int tp_batch_run(tp_batch_t b);                             /* async on the handle's stream; HIP-event timed */
+int tp_batch_download(tp_batch_t b, double* weights /* [W x k] */, int32_t* status /* [W] */,
+                      double* aux /* optional [W x TP_AUX_STRIDE] */); /* waits for the stream, D2H */
+int tp_batch_download_S1(tp_batch_t b, int64_t w, double* S1 /* [k x k] */); /* posterior scale matrix
+                      S1 (ref:358) / Jeffreys J (ref:600) of window w, recomputed by a debug launch */
+int tp_batch_destroy(tp_batch_t b);
+
+/* One-shot convenience: upload + run + download.  Replaces
+ * calculate_conjugate_hf_mcm_portfolio (ref:819) / calculate_jeffreys_portfolio (ref:838) over W dates. */
+int tp_posterior_batch(tp_handle_t h, const tp_params_t* p, int64_t W, const tp_inputs_t* in,
+                       double* weights, int32_t* status, double* aux);
+
+int tp_synchronize(tp_handle_t h);
+/* Timings of the most recent call of each kind on this handle, in milliseconds (HIP events on the
+ * handle's stream): posterior kernel, H2D upload, D2H download, RCCL gather. */
+int tp_last_timing(tp_handle_t h, double* kernel_ms, double* h2d_ms, double* d2h_ms, double* gather_ms);
+/* HIP-event bracket on the handle's stream around any sequence of tp_batch_run calls (bench.py's
+ * timed region): begin records an event, end records another, waits for it and returns the span. */
+int tp_region_begin(tp_handle_t h);
+int tp_region_end(tp_handle_t h, double* ms);
+/* Launch geometry of the most recent tp_batch_run: grid size, threads per workgroup, LDS bytes,
+ * 16-column tile count per side. */
+int tp_last_launch(tp_handle_t h, int* grid, int* block, int* lds_bytes, int* ntile);
+
+/* Multi-GPU: one process (handle) per GPU; windows are sharded by the caller; the only data-path
+ * collective is one gather of the [W_local x k] weights (and statuses) to `root` over RCCL/xGMI.
+ * The 128-byte id comes from rank 0 (tp_comm_unique_id) and is distributed by the launcher. */
+#define TP_UNIQUE_ID_BYTES 128
+int tp_comm_unique_id(void* id /* [TP_UNIQUE_ID_BYTES] */);
+int tp_comm_init(tp_handle_t h, const void* id, int rank, int world);
+int tp_comm_destroy(tp_handle_t h);
+/* Every rank calls it with the same W_local; on root, weights_all [world x W x k] and
+ * status_all [world x W] are HOST buffers filled after the gather (NULL elsewhere). */
+int tp_batch_gather(tp_batch_t b, int root, double* weights_all, int32_t* status_all);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TANGENCY_POSTERIOR_H */

@@ -1,0 +1,303 @@
+"""ctypes binding of libtangency.so (include/tangency_posterior.h).
+
+This is the ONLY compute path of the package: there is no CPU fallback.  Importing the module loads
+the shared library (so that a missing build fails loudly); creating a `Device` needs a gfx950 GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtangency.so")
+
+TP_OK = 0
+TP_ERR_INVALID = -1
+TP_ERR_NO_DEVICE = -2
+TP_ERR_HIP = -3
+TP_ERR_UNSUPPORTED = -4
+TP_ERR_RCCL = -5
+STRATEGY_CONJUGATE = 0
+STRATEGY_JEFFREYS = 1
+STATUS_OK, STATUS_NOT_PD, STATUS_NONFINITE, STATUS_BAD_DENOM = 0, 1, 2, 3
+AUX_STRIDE = 8
+UNIQUE_ID_BYTES = 128
+
+# every symbol include/tangency_posterior.h declares (checked by tests/test_cabi_symbols.py)
+EXPORTS = [
+    "tp_version", "tp_max_assets", "tp_create", "tp_destroy", "tp_last_error", "tp_device_info",
+    "tp_batch_create", "tp_batch_upload", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1",
+    "tp_batch_destroy", "tp_posterior_batch", "tp_synchronize", "tp_last_timing", "tp_region_begin",
+    "tp_region_end", "tp_last_launch", "tp_comm_unique_id", "tp_comm_init", "tp_comm_destroy",
+    "tp_batch_gather",
+]
+
+
+class TangencyError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libtangency error {code}: {msg}")
+        self.code = code
+
+
+class tp_params_t(ctypes.Structure):
+    _fields_ = [("k", c_int32), ("N", c_int32), ("n_r", c_int32), ("m", c_int32), ("strategy", c_int32),
+                ("reserved", c_int32), ("gamma", c_double)]
+
+
+class tp_inputs_t(ctypes.Structure):
+    _fields_ = [("panel", POINTER(c_double)), ("panel_rows", c_int64), ("panel_ld", c_int32), ("hf_ld", c_int32),
+                ("start", POINTER(c_int64)), ("row_idx", POINTER(c_int32)), ("n_rows", POINTER(c_int32)),
+                ("col_idx", POINTER(c_int32)), ("rf_adj", POINTER(c_double)),
+                ("hf_panel", POINTER(c_double)), ("hf_rows", c_int64),
+                ("hf_start", POINTER(c_int64)), ("hf_row_idx", POINTER(c_int32)), ("hf_count", POINTER(c_int32)),
+                ("w0", POINTER(c_double)), ("n0", POINTER(c_double))]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C incorporating_different_sources_amd/csrc`.  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.tp_version.restype = c_char_p
+    lib.tp_last_error.restype = c_char_p
+    lib.tp_last_error.argtypes = [c_void_p]
+    lib.tp_max_assets.restype = c_int
+    lib.tp_create.argtypes = [c_int, POINTER(c_void_p)]
+    lib.tp_destroy.argtypes = [c_void_p]
+    lib.tp_device_info.argtypes = [c_void_p, c_char_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int64)]
+    lib.tp_batch_create.argtypes = [c_void_p, POINTER(tp_params_t), c_int64, POINTER(c_void_p)]
+    lib.tp_batch_upload.argtypes = [c_void_p, POINTER(tp_inputs_t)]
+    lib.tp_batch_run.argtypes = [c_void_p]
+    lib.tp_batch_download.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int32), POINTER(c_double)]
+    lib.tp_batch_download_S1.argtypes = [c_void_p, c_int64, POINTER(c_double)]
+    lib.tp_batch_destroy.argtypes = [c_void_p]
+    lib.tp_posterior_batch.argtypes = [c_void_p, POINTER(tp_params_t), c_int64, POINTER(tp_inputs_t),
+                                       POINTER(c_double), POINTER(c_int32), POINTER(c_double)]
+    lib.tp_synchronize.argtypes = [c_void_p]
+    lib.tp_last_timing.argtypes = [c_void_p] + [POINTER(c_double)] * 4
+    lib.tp_region_begin.argtypes = [c_void_p]
+    lib.tp_region_end.argtypes = [c_void_p, POINTER(c_double)]
+    lib.tp_last_launch.argtypes = [c_void_p] + [POINTER(c_int)] * 4
+    lib.tp_comm_unique_id.argtypes = [c_void_p]
+    lib.tp_comm_init.argtypes = [c_void_p, c_void_p, c_int, c_int]
+    lib.tp_comm_destroy.argtypes = [c_void_p]
+    lib.tp_batch_gather.argtypes = [c_void_p, c_int, POINTER(c_double), POINTER(c_int32)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is not c_char_p:
+            fn.restype = c_int
+    return lib
+
+
+lib = _load()
+
+
+def version() -> str:
+    return lib.tp_version().decode()
+
+
+def max_assets() -> int:
+    return int(lib.tp_max_assets())
+
+
+def _ptr(a, ct):
+    return None if a is None else a.ctypes.data_as(POINTER(ct))
+
+
+def _arr(a, dtype, shape=None, name=""):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(a.shape)}")
+    return a
+
+
+class Device:
+    """One GPU (`tp_handle_t`): a HIP stream, timing events and optionally an RCCL communicator."""
+
+    def __init__(self, device_id: int = 0):
+        self._h = c_void_p()
+        rc = lib.tp_create(int(device_id), ctypes.byref(self._h))
+        if rc != TP_OK:
+            raise TangencyError(rc, lib.tp_last_error(None).decode())
+        self.device_id = device_id
+
+    def _check(self, rc):
+        if rc != TP_OK:
+            raise TangencyError(rc, lib.tp_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            lib.tp_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self) -> dict:
+        name = ctypes.create_string_buffer(256)
+        cu, mhz, hbm = c_int(), c_int(), c_int64()
+        self._check(lib.tp_device_info(self._h, name, 256, ctypes.byref(cu), ctypes.byref(mhz), ctypes.byref(hbm)))
+        return dict(name=name.value.decode(), compute_units=cu.value, clock_mhz=mhz.value, hbm_bytes=hbm.value)
+
+    def synchronize(self):
+        self._check(lib.tp_synchronize(self._h))
+
+    def last_timing(self) -> dict:
+        v = [c_double() for _ in range(4)]
+        self._check(lib.tp_last_timing(self._h, *[ctypes.byref(x) for x in v]))
+        return dict(kernel_ms=v[0].value, h2d_ms=v[1].value, d2h_ms=v[2].value, gather_ms=v[3].value)
+
+    def last_launch(self) -> dict:
+        v = [c_int() for _ in range(4)]
+        self._check(lib.tp_last_launch(self._h, *[ctypes.byref(x) for x in v]))
+        return dict(grid=v[0].value, block=v[1].value, lds_bytes=v[2].value, ntile=v[3].value)
+
+    def region_begin(self):
+        self._check(lib.tp_region_begin(self._h))
+
+    def region_end(self) -> float:
+        ms = c_double()
+        self._check(lib.tp_region_end(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    # ---- RCCL -------------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+        rc = lib.tp_comm_unique_id(buf)
+        if rc != TP_OK:
+            raise TangencyError(rc, "ncclGetUniqueId failed")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        buf = ctypes.create_string_buffer(unique_id, UNIQUE_ID_BYTES)
+        self._check(lib.tp_comm_init(self._h, buf, int(rank), int(world)))
+        self.rank, self.world = rank, world
+
+    def comm_destroy(self):
+        self._check(lib.tp_comm_destroy(self._h))
+
+    # ---- batches ------------------------------------------------------------------------------
+    def batch(self, strategy, k, N, n_r, gamma, W, m=0) -> "Batch":
+        return Batch(self, strategy, k, N, n_r, gamma, W, m)
+
+
+class Batch:
+    """W windows resident in HBM (`tp_batch_t`)."""
+
+    def __init__(self, dev: Device, strategy, k, N, n_r, gamma, W, m=0):
+        self.dev = dev
+        strat = {"conjugate": STRATEGY_CONJUGATE, "jeffreys": STRATEGY_JEFFREYS}.get(strategy, strategy)
+        self.params = tp_params_t(int(k), int(N), int(n_r), int(m), int(strat), 0, float(gamma))
+        self.W, self.k, self.n_r, self.m = int(W), int(k), int(n_r), int(m)
+        self._b = c_void_p()
+        dev._check(lib.tp_batch_create(dev._h, ctypes.byref(self.params), self.W, ctypes.byref(self._b)))
+        self._keep = None
+
+    def close(self):
+        if self._b:
+            lib.tp_batch_destroy(self._b)
+            self._b = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, panel, start=None, hf_panel=None, hf_start=None, w0=None, n0=None, row_idx=None,
+               n_rows=None, col_idx=None, rf_adj=None, hf_row_idx=None, hf_count=None):
+        W, k, n_r, m = self.W, self.k, self.n_r, self.m
+        panel = _arr(panel, np.float64)
+        if panel.ndim != 2:
+            raise ValueError("panel must be 2-D [rows x assets]")
+        hf_panel = _arr(hf_panel, np.float64)
+        if hf_panel is not None and hf_panel.ndim != 2:
+            raise ValueError("hf_panel must be 2-D [rows x assets]")
+        a = dict(
+            panel=panel, hf_panel=hf_panel,
+            start=_arr(start, np.int64, (W,), "start"), row_idx=_arr(row_idx, np.int32, (W, n_r), "row_idx"),
+            n_rows=_arr(n_rows, np.int32, (W,), "n_rows"), col_idx=_arr(col_idx, np.int32, (W, k), "col_idx"),
+            rf_adj=_arr(rf_adj, np.float64, (W, n_r), "rf_adj"),
+            hf_start=_arr(hf_start, np.int64, (W,), "hf_start"),
+            hf_row_idx=_arr(hf_row_idx, np.int32, (W, m), "hf_row_idx"),
+            hf_count=_arr(hf_count, np.int32, (W,), "hf_count"),
+            w0=_arr(w0, np.float64, (W, k), "w0"), n0=_arr(n0, np.float64, (W,), "n0"))
+        inp = tp_inputs_t(
+            _ptr(a["panel"], c_double), panel.shape[0], panel.shape[1],
+            hf_panel.shape[1] if hf_panel is not None else 0,
+            _ptr(a["start"], c_int64), _ptr(a["row_idx"], c_int32), _ptr(a["n_rows"], c_int32),
+            _ptr(a["col_idx"], c_int32), _ptr(a["rf_adj"], c_double),
+            _ptr(a["hf_panel"], c_double), hf_panel.shape[0] if hf_panel is not None else 0,
+            _ptr(a["hf_start"], c_int64), _ptr(a["hf_row_idx"], c_int32), _ptr(a["hf_count"], c_int32),
+            _ptr(a["w0"], c_double), _ptr(a["n0"], c_double))
+        self._keep = a     # host arrays stay alive for the duration of the (synchronous) upload
+        self.dev._check(lib.tp_batch_upload(self._b, ctypes.byref(inp)))
+        self._keep = None
+        return self
+
+    def run(self):
+        self.dev._check(lib.tp_batch_run(self._b))
+        return self
+
+    def download(self, want_aux=True):
+        weights = np.empty((self.W, self.k), dtype=np.float64)
+        status = np.empty(self.W, dtype=np.int32)
+        aux = np.empty((self.W, AUX_STRIDE), dtype=np.float64) if want_aux else None
+        self.dev._check(lib.tp_batch_download(self._b, _ptr(weights, c_double), _ptr(status, c_int32),
+                                              _ptr(aux, c_double)))
+        return weights, status, aux
+
+    def download_S1(self, w: int) -> np.ndarray:
+        S1 = np.empty((self.k, self.k), dtype=np.float64)
+        self.dev._check(lib.tp_batch_download_S1(self._b, int(w), _ptr(S1, c_double)))
+        return S1
+
+    def gather(self, root=0):
+        """One RCCL gather of every rank's [W x k] weights (and statuses) to `root`."""
+        world, rank = self.dev.world, self.dev.rank
+        if rank == root:
+            wall = np.empty((world, self.W, self.k), dtype=np.float64)
+            sall = np.empty((world, self.W), dtype=np.int32)
+            self.dev._check(lib.tp_batch_gather(self._b, root, _ptr(wall, c_double), _ptr(sall, c_int32)))
+            return wall, sall
+        self.dev._check(lib.tp_batch_gather(self._b, root, None, None))
+        return None, None
+
+
+_default_device = None
+
+
+def default_device() -> Device:
+    global _default_device
+    if _default_device is None:
+        _default_device = Device(int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("TP_DEVICE") is None
+                                 else int(os.environ["TP_DEVICE"]))
+    return _default_device
+
+
+def posterior_batch(strategy, k, N, gamma, panel, start=None, n_r=None, hf_panel=None, hf_start=None, m=0,
+                    w0=None, n0=None, row_idx=None, n_rows=None, col_idx=None, rf_adj=None,
+                    hf_row_idx=None, hf_count=None, device: Device | None = None, want_aux=True):
+    """Upload + run + download.  Same argument meaning as `oracle.posterior_batch` (tests compare them)."""
+    dev = device or default_device()
+    W = len(start) if start is not None else len(row_idx)
+    b = Batch(dev, strategy, k, N, n_r, gamma, W, m or 0)
+    try:
+        b.upload(panel, start=start, hf_panel=hf_panel, hf_start=hf_start, w0=w0, n0=n0, row_idx=row_idx,
+                 n_rows=n_rows, col_idx=col_idx, rf_adj=rf_adj, hf_row_idx=hf_row_idx, hf_count=hf_count)
+        b.run()
+        return b.download(want_aux=want_aux)
+    finally:
+        b.close()

@@ -1,0 +1,41 @@
+// posterior_kernels.h - internal interface between the C-ABI (tangency_api.cpp) and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TP_KSTATUS_OK 0
+#define TP_KSTATUS_NOT_PD 1
+#define TP_KSTATUS_NONFINITE 2
+#define TP_KSTATUS_BAD_DENOM 3
+
+// Device-side view of one batch (all pointers are DEVICE pointers; optional ones may be null).
+struct tp_kargs_t {
+    const double* panel;
+    const long long* start;
+    const int* row_idx;
+    const int* n_rows;
+    const int* col_idx;
+    const double* rf_adj;
+    const double* hf_panel;
+    const long long* hf_start;
+    const int* hf_row_idx;
+    const int* hf_count;
+    const double* w0;
+    const double* n0;
+    double* weights;
+    int* status;
+    double* aux;
+    double* dbg_S1;       // optional [k*k + k]: S1 (or J) and the right-hand side of window dbg_w
+    long long dbg_w;
+    long long w_first, w_count;
+    int panel_ld, hf_ld;
+    int k, N, n_r, m, strategy;
+    double gamma;
+};
+
+struct tp_launch_info_t { int grid, block, lds_bytes, ntile; };
+
+// register-tile fused kernel (posterior_fused.hip): k <= tp_fused_max_assets()
+int tp_fused_max_assets(void);
+hipError_t tp_fused_launch(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info,
+                           int* want_occupancy);

@@ -1,0 +1,521 @@
+// tangency_api.cpp - C-ABI of libtangency.so (include/tangency_posterior.h): contexts, device
+// buffers, launches, timing and the RCCL gather.  Compiled with hipcc; no kernels in this file.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/tangency_posterior.h"
+#include "posterior_kernels.h"
+
+static_assert(TP_STATUS_NOT_PD == TP_KSTATUS_NOT_PD && TP_STATUS_NONFINITE == TP_KSTATUS_NONFINITE &&
+              TP_STATUS_BAD_DENOM == TP_KSTATUS_BAD_DENOM, "status codes out of sync");
+static_assert(TP_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+
+namespace {
+thread_local std::string g_create_error;
+}
+
+struct tp_handle_s {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, reg0 = nullptr, reg1 = nullptr;
+    hipDeviceProp_t prop;
+    std::string err;
+    double kernel_ms = 0, h2d_ms = 0, d2h_ms = 0, gather_ms = 0;
+    tp_launch_info_t last_launch{0, 0, 0, 0};
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    bool kernel_timed = false;   // ev0/ev1 bracket the last tp_batch_run and have not been read yet
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct tp_batch_s {
+    tp_handle_t h = nullptr;
+    tp_params_t p{};
+    int64_t W = 0;
+    int panel_ld = 0, hf_ld = 0;
+    DevBuf panel, start, row_idx, n_rows, col_idx, rf_adj, hf_panel, hf_start, hf_row_idx, hf_count, w0, n0;
+    DevBuf weights, status, aux, dbg, gather_w, gather_s;
+    bool uploaded = false;
+};
+
+namespace {
+
+int fail(tp_handle_t h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    return fail((h), TP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define NCCL_TRY(h, expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) \
+    return fail((h), TP_ERR_RCCL, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_), __FILE__, __LINE__); } while (0)
+
+int ensure(tp_handle_t h, DevBuf& b, size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    if (b.bytes >= bytes) return TP_OK;
+    if (b.p) { HIP_TRY(h, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    HIP_TRY(h, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return TP_OK;
+}
+
+int put(tp_handle_t h, DevBuf& b, const void* src, size_t bytes) {
+    if (!src) {   // optional input absent: drop any stale copy
+        if (b.p) { HIP_TRY(h, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+        return TP_OK;
+    }
+    int rc = ensure(h, b, bytes);
+    if (rc != TP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, h->stream));
+    return TP_OK;
+}
+
+void release(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+int check_params(tp_handle_t h, const tp_params_t* p, int64_t W) {
+    if (!p) return fail(h, TP_ERR_INVALID, "params is NULL");
+    if (W < 0) return fail(h, TP_ERR_INVALID, "W=%lld < 0", (long long)W);
+    if (p->k < 1) return fail(h, TP_ERR_INVALID, "k=%d < 1", p->k);
+    if (p->N < 1 || p->n_r < 1) return fail(h, TP_ERR_INVALID, "N=%d n_r=%d must be >= 1", p->N, p->n_r);
+    if (p->strategy != TP_STRATEGY_CONJUGATE && p->strategy != TP_STRATEGY_JEFFREYS)
+        return fail(h, TP_ERR_INVALID, "unknown strategy %d", p->strategy);
+    if (p->strategy == TP_STRATEGY_CONJUGATE && p->m < 2)
+        return fail(h, TP_ERR_INVALID, "conjugate prior needs m >= 2 intraday returns (m=%d)", p->m);
+    if (!(p->gamma > 0.0) && !(p->gamma < 0.0)) return fail(h, TP_ERR_INVALID, "gamma must be non-zero");
+    if (p->k > tp_max_assets())
+        return fail(h, TP_ERR_UNSUPPORTED, "k=%d exceeds the register-tile kernel's limit %d", p->k, tp_max_assets());
+    return TP_OK;
+}
+
+tp_kargs_t make_kargs(tp_batch_t b) {
+    tp_kargs_t a;
+    memset(&a, 0, sizeof a);
+    a.panel = (const double*)b->panel.p;
+    a.start = (const long long*)b->start.p;
+    a.row_idx = (const int*)b->row_idx.p;
+    a.n_rows = (const int*)b->n_rows.p;
+    a.col_idx = (const int*)b->col_idx.p;
+    a.rf_adj = (const double*)b->rf_adj.p;
+    a.hf_panel = (const double*)b->hf_panel.p;
+    a.hf_start = (const long long*)b->hf_start.p;
+    a.hf_row_idx = (const int*)b->hf_row_idx.p;
+    a.hf_count = (const int*)b->hf_count.p;
+    a.w0 = (const double*)b->w0.p;
+    a.n0 = (const double*)b->n0.p;
+    a.weights = (double*)b->weights.p;
+    a.status = (int*)b->status.p;
+    a.aux = (double*)b->aux.p;
+    a.dbg_S1 = nullptr;
+    a.dbg_w = -1;
+    a.w_first = 0;
+    a.w_count = b->W;
+    a.panel_ld = b->panel_ld;
+    a.hf_ld = b->hf_ld;
+    a.k = b->p.k; a.N = b->p.N; a.n_r = b->p.n_r; a.m = b->p.m; a.strategy = b->p.strategy;
+    a.gamma = b->p.gamma;
+    return a;
+}
+
+// Host-side validation of every index the kernel will dereference: a bad offset must never reach
+// the device (an out-of-bounds access can take the whole node down).
+int validate_inputs(tp_handle_t h, const tp_params_t& p, int64_t W, const tp_inputs_t* in) {
+    if (!in) return fail(h, TP_ERR_INVALID, "inputs is NULL");
+    if (!in->panel || in->panel_rows < 1 || in->panel_ld < 1) return fail(h, TP_ERR_INVALID, "panel missing");
+    if (!in->start && !in->row_idx) return fail(h, TP_ERR_INVALID, "need start[] or row_idx[]");
+    const bool conj = p.strategy == TP_STRATEGY_CONJUGATE;
+    if (conj) {
+        if (!in->hf_panel || in->hf_rows < 1 || in->hf_ld < 1) return fail(h, TP_ERR_INVALID, "hf_panel missing");
+        if (!in->hf_start && !in->hf_row_idx) return fail(h, TP_ERR_INVALID, "need hf_start[] or hf_row_idx[]");
+        if (!in->w0 || !in->n0) return fail(h, TP_ERR_INVALID, "conjugate prior needs w0[] and n0[]");
+    }
+    const int ncol_need = in->col_idx ? 0 : p.k;
+    if (ncol_need > in->panel_ld) return fail(h, TP_ERR_INVALID, "panel_ld=%d < k=%d", in->panel_ld, p.k);
+    if (conj && ncol_need > in->hf_ld) return fail(h, TP_ERR_INVALID, "hf_ld=%d < k=%d", in->hf_ld, p.k);
+    for (int64_t w = 0; w < W; ++w) {
+        const int nr = in->n_rows ? in->n_rows[w] : p.n_r;
+        if (nr < 1 || nr > p.n_r) return fail(h, TP_ERR_INVALID, "n_rows[%lld]=%d outside [1,%d]", (long long)w, nr, p.n_r);
+        if (in->row_idx) {
+            for (int r = 0; r < nr; ++r) {
+                const int64_t row = in->row_idx[w * (int64_t)p.n_r + r];
+                if (row < 0 || row >= in->panel_rows)
+                    return fail(h, TP_ERR_INVALID, "row_idx[%lld][%d]=%lld outside the panel", (long long)w, r, (long long)row);
+            }
+        } else if (in->start[w] < 0 || in->start[w] + nr > in->panel_rows) {
+            return fail(h, TP_ERR_INVALID, "window %lld rows [%lld,%lld) outside the panel (%lld rows)", (long long)w,
+                        (long long)in->start[w], (long long)(in->start[w] + nr), (long long)in->panel_rows);
+        }
+        if (in->col_idx) {
+            for (int j = 0; j < p.k; ++j) {
+                const int c = in->col_idx[w * (int64_t)p.k + j];
+                if (c < 0 || c >= in->panel_ld || (conj && c >= in->hf_ld))
+                    return fail(h, TP_ERR_INVALID, "col_idx[%lld][%d]=%d outside the panel", (long long)w, j, c);
+            }
+        }
+        if (conj) {
+            const int mm = in->hf_count ? in->hf_count[w] : p.m;
+            if (mm < 2 || mm > p.m) return fail(h, TP_ERR_INVALID, "hf_count[%lld]=%d outside [2,%d]", (long long)w, mm, p.m);
+            if (in->hf_row_idx) {
+                for (int r = 0; r < mm; ++r) {
+                    const int64_t row = in->hf_row_idx[w * (int64_t)p.m + r];
+                    if (row < 0 || row >= in->hf_rows)
+                        return fail(h, TP_ERR_INVALID, "hf_row_idx[%lld][%d]=%lld outside the panel", (long long)w, r, (long long)row);
+                }
+            } else if (in->hf_start[w] < 0 || in->hf_start[w] + mm > in->hf_rows) {
+                return fail(h, TP_ERR_INVALID, "window %lld intraday rows [%lld,%lld) outside the panel (%lld rows)",
+                            (long long)w, (long long)in->hf_start[w], (long long)(in->hf_start[w] + mm), (long long)in->hf_rows);
+            }
+        }
+    }
+    return TP_OK;
+}
+
+int launch(tp_batch_t b, const tp_kargs_t& a, int64_t count, bool timed) {
+    tp_handle_t h = b->h;
+    if (count <= 0) return TP_OK;
+    if (count > 0x7fffffffLL) return fail(h, TP_ERR_INVALID, "too many windows in one launch");
+    if (timed) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    hipError_t e = tp_fused_launch(a, (int)count, h->stream, &h->last_launch, nullptr);
+    if (e != hipSuccess) return fail(h, TP_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    if (timed) { HIP_TRY(h, hipEventRecord(h->ev1, h->stream)); h->kernel_timed = true; }
+    return TP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tp_version(void) { return "tangency-posterior 0.1.0 (gfx950, fp64 MFMA register-tile kernel)"; }
+
+int tp_max_assets(void) { return tp_fused_max_assets(); }
+
+const char* tp_last_error(tp_handle_t h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int tp_create(int device_id, tp_handle_t* out) {
+    if (!out) return fail(nullptr, TP_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n < 1)
+        return fail(nullptr, TP_ERR_NO_DEVICE, "no HIP device available (%s); there is no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, TP_ERR_INVALID, "device %d out of range (0..%d)", device_id, n - 1);
+    tp_handle_t h = new (std::nothrow) tp_handle_s();
+    if (!h) return fail(nullptr, TP_ERR_INVALID, "out of host memory");
+    h->device = device_id;
+#define CREATE_TRY(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) { \
+        int rc_ = fail(nullptr, TP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e2_)); delete h; return rc_; } } while (0)
+    CREATE_TRY(hipSetDevice(device_id));
+    CREATE_TRY(hipGetDeviceProperties(&h->prop, device_id));
+    if (strncmp(h->prop.gcnArchName, "gfx950", 6) != 0) {
+        int rc = fail(nullptr, TP_ERR_NO_DEVICE, "device %d is %s; libtangency is built for gfx950 only", device_id,
+                      h->prop.gcnArchName);
+        delete h;
+        return rc;
+    }
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreate(&h->ev0));
+    CREATE_TRY(hipEventCreate(&h->ev1));
+    CREATE_TRY(hipEventCreate(&h->reg0));
+    CREATE_TRY(hipEventCreate(&h->reg1));
+#undef CREATE_TRY
+    *out = h;
+    return TP_OK;
+}
+
+int tp_destroy(tp_handle_t h) {
+    if (!h) return TP_OK;
+    (void)hipSetDevice(h->device);
+    if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->reg0) (void)hipEventDestroy(h->reg0);
+    if (h->reg1) (void)hipEventDestroy(h->reg1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return TP_OK;
+}
+
+int tp_device_info(tp_handle_t h, char* name, int name_len, int* compute_units, int* clock_mhz, int64_t* hbm_bytes) {
+    if (!h) return TP_ERR_INVALID;
+    if (name && name_len > 0) { snprintf(name, (size_t)name_len, "%s (%s)", h->prop.name, h->prop.gcnArchName); }
+    if (compute_units) *compute_units = h->prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = h->prop.clockRate / 1000;
+    if (hbm_bytes) *hbm_bytes = (int64_t)h->prop.totalGlobalMem;
+    return TP_OK;
+}
+
+int tp_batch_create(tp_handle_t h, const tp_params_t* p, int64_t W, tp_batch_t* out) {
+    if (!h || !out) return TP_ERR_INVALID;
+    *out = nullptr;
+    int rc = check_params(h, p, W);
+    if (rc != TP_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    tp_batch_t b = new (std::nothrow) tp_batch_s();
+    if (!b) return fail(h, TP_ERR_INVALID, "out of host memory");
+    b->h = h; b->p = *p; b->W = W;
+    rc = ensure(h, b->weights, sizeof(double) * (size_t)W * p->k);
+    if (rc == TP_OK) rc = ensure(h, b->status, sizeof(int32_t) * (size_t)W);
+    if (rc == TP_OK) rc = ensure(h, b->aux, sizeof(double) * (size_t)W * TP_AUX_STRIDE);
+    if (rc != TP_OK) { tp_batch_destroy(b); return rc; }
+    *out = b;
+    return TP_OK;
+}
+
+int tp_batch_destroy(tp_batch_t b) {
+    if (!b) return TP_OK;
+    (void)hipSetDevice(b->h->device);
+    (void)hipStreamSynchronize(b->h->stream);
+    DevBuf* all[] = {&b->panel, &b->start, &b->row_idx, &b->n_rows, &b->col_idx, &b->rf_adj, &b->hf_panel, &b->hf_start,
+                     &b->hf_row_idx, &b->hf_count, &b->w0, &b->n0, &b->weights, &b->status, &b->aux, &b->dbg,
+                     &b->gather_w, &b->gather_s};
+    for (DevBuf* d : all) release(*d);
+    delete b;
+    return TP_OK;
+}
+
+int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in) {
+    if (!b) return TP_ERR_INVALID;
+    tp_handle_t h = b->h;
+    const tp_params_t& p = b->p;
+    const int64_t W = b->W;
+    int rc = validate_inputs(h, p, W, in);
+    if (rc != TP_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const bool conj = p.strategy == TP_STRATEGY_CONJUGATE;
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    h->kernel_timed = false;
+#define PUT(buf, ptr, bytes) do { rc = put(h, b->buf, (ptr), (bytes)); if (rc != TP_OK) return rc; } while (0)
+    PUT(panel, in->panel, sizeof(double) * (size_t)in->panel_rows * in->panel_ld);
+    PUT(start, in->start, sizeof(int64_t) * (size_t)W);
+    PUT(row_idx, in->row_idx, sizeof(int32_t) * (size_t)W * p.n_r);
+    PUT(n_rows, in->n_rows, sizeof(int32_t) * (size_t)W);
+    PUT(col_idx, in->col_idx, sizeof(int32_t) * (size_t)W * p.k);
+    PUT(rf_adj, in->rf_adj, sizeof(double) * (size_t)W * p.n_r);
+    if (conj) {
+        PUT(hf_panel, in->hf_panel, sizeof(double) * (size_t)in->hf_rows * in->hf_ld);
+        PUT(hf_start, in->hf_start, sizeof(int64_t) * (size_t)W);
+        PUT(hf_row_idx, in->hf_row_idx, sizeof(int32_t) * (size_t)W * p.m);
+        PUT(hf_count, in->hf_count, sizeof(int32_t) * (size_t)W);
+        PUT(w0, in->w0, sizeof(double) * (size_t)W * p.k);
+        PUT(n0, in->n0, sizeof(double) * (size_t)W);
+    }
+#undef PUT
+    b->panel_ld = in->panel_ld;
+    b->hf_ld = conj ? in->hf_ld : 0;
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    float ms = 0;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->h2d_ms = ms;
+    b->uploaded = true;
+    return TP_OK;
+}
+
+int tp_batch_run(tp_batch_t b) {
+    if (!b) return TP_ERR_INVALID;
+    tp_handle_t h = b->h;
+    if (!b->uploaded) return fail(h, TP_ERR_INVALID, "tp_batch_run before tp_batch_upload");
+    HIP_TRY(h, hipSetDevice(h->device));
+    tp_kargs_t a = make_kargs(b);
+    return launch(b, a, b->W, true);
+}
+
+static int harvest_kernel_time(tp_handle_t h) {
+    if (h->kernel_timed) {
+        HIP_TRY(h, hipEventSynchronize(h->ev1));
+        float ms = 0;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        h->kernel_ms = ms;
+        h->kernel_timed = false;
+    }
+    return TP_OK;
+}
+
+int tp_synchronize(tp_handle_t h) {
+    if (!h) return TP_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return harvest_kernel_time(h);
+}
+
+int tp_batch_download(tp_batch_t b, double* weights, int32_t* status, double* aux) {
+    if (!b) return TP_ERR_INVALID;
+    tp_handle_t h = b->h;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    int rc = harvest_kernel_time(h);
+    if (rc != TP_OK) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    if (weights) HIP_TRY(h, hipMemcpyAsync(weights, b->weights.p, sizeof(double) * (size_t)b->W * b->p.k, hipMemcpyDeviceToHost, h->stream));
+    if (status) HIP_TRY(h, hipMemcpyAsync(status, b->status.p, sizeof(int32_t) * (size_t)b->W, hipMemcpyDeviceToHost, h->stream));
+    if (aux) HIP_TRY(h, hipMemcpyAsync(aux, b->aux.p, sizeof(double) * (size_t)b->W * TP_AUX_STRIDE, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    float ms = 0;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->d2h_ms = ms;
+    return TP_OK;
+}
+
+int tp_batch_download_S1(tp_batch_t b, int64_t w, double* S1) {
+    if (!b || !S1) return TP_ERR_INVALID;
+    tp_handle_t h = b->h;
+    if (!b->uploaded) return fail(h, TP_ERR_INVALID, "tp_batch_download_S1 before tp_batch_upload");
+    if (w < 0 || w >= b->W) return fail(h, TP_ERR_INVALID, "window %lld out of range", (long long)w);
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t kk = (size_t)b->p.k * b->p.k;
+    int rc = ensure(h, b->dbg, sizeof(double) * (kk + b->p.k));
+    if (rc != TP_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    rc = harvest_kernel_time(h);
+    if (rc != TP_OK) return rc;
+    tp_kargs_t a = make_kargs(b);
+    a.dbg_S1 = (double*)b->dbg.p;
+    a.dbg_w = w;
+    a.w_first = w;
+    a.w_count = 1;
+    rc = launch(b, a, 1, false);
+    if (rc != TP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(S1, b->dbg.p, sizeof(double) * kk, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return TP_OK;
+}
+
+int tp_posterior_batch(tp_handle_t h, const tp_params_t* p, int64_t W, const tp_inputs_t* in, double* weights,
+                       int32_t* status, double* aux) {
+    tp_batch_t b = nullptr;
+    int rc = tp_batch_create(h, p, W, &b);
+    if (rc != TP_OK) return rc;
+    rc = tp_batch_upload(b, in);
+    if (rc == TP_OK) rc = tp_batch_run(b);
+    if (rc == TP_OK) rc = tp_batch_download(b, weights, status, aux);
+    tp_batch_destroy(b);
+    return rc;
+}
+
+int tp_last_timing(tp_handle_t h, double* kernel_ms, double* h2d_ms, double* d2h_ms, double* gather_ms) {
+    if (!h) return TP_ERR_INVALID;
+    if (kernel_ms) *kernel_ms = h->kernel_ms;
+    if (h2d_ms) *h2d_ms = h->h2d_ms;
+    if (d2h_ms) *d2h_ms = h->d2h_ms;
+    if (gather_ms) *gather_ms = h->gather_ms;
+    return TP_OK;
+}
+
+int tp_region_begin(tp_handle_t h) {
+    if (!h) return TP_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventRecord(h->reg0, h->stream));
+    return TP_OK;
+}
+
+int tp_region_end(tp_handle_t h, double* ms) {
+    if (!h) return TP_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventRecord(h->reg1, h->stream));
+    HIP_TRY(h, hipEventSynchronize(h->reg1));
+    float f = 0;
+    HIP_TRY(h, hipEventElapsedTime(&f, h->reg0, h->reg1));
+    if (ms) *ms = f;
+    return harvest_kernel_time(h);
+}
+
+int tp_last_launch(tp_handle_t h, int* grid, int* block, int* lds_bytes, int* ntile) {
+    if (!h) return TP_ERR_INVALID;
+    if (grid) *grid = h->last_launch.grid;
+    if (block) *block = h->last_launch.block;
+    if (lds_bytes) *lds_bytes = h->last_launch.lds_bytes;
+    if (ntile) *ntile = h->last_launch.ntile;
+    return TP_OK;
+}
+
+int tp_comm_unique_id(void* id) {
+    if (!id) return TP_ERR_INVALID;
+    ncclUniqueId uid;
+    if (ncclGetUniqueId(&uid) != ncclSuccess) return TP_ERR_RCCL;
+    memcpy(id, &uid, sizeof uid);
+    return TP_OK;
+}
+
+int tp_comm_init(tp_handle_t h, const void* id, int rank, int world) {
+    if (!h || !id) return TP_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world) return fail(h, TP_ERR_INVALID, "bad rank %d / world %d", rank, world);
+    if (h->comm) return fail(h, TP_ERR_INVALID, "communicator already initialised");
+    HIP_TRY(h, hipSetDevice(h->device));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    NCCL_TRY(h, ncclCommInitRank(&h->comm, world, uid, rank));
+    h->rank = rank;
+    h->world = world;
+    return TP_OK;
+}
+
+int tp_comm_destroy(tp_handle_t h) {
+    if (!h) return TP_ERR_INVALID;
+    if (h->comm) { NCCL_TRY(h, ncclCommDestroy(h->comm)); h->comm = nullptr; }
+    h->world = 1; h->rank = 0;
+    return TP_OK;
+}
+
+int tp_batch_gather(tp_batch_t b, int root, double* weights_all, int32_t* status_all) {
+    if (!b) return TP_ERR_INVALID;
+    tp_handle_t h = b->h;
+    if (!h->comm) return fail(h, TP_ERR_INVALID, "tp_batch_gather without tp_comm_init");
+    if (root < 0 || root >= h->world) return fail(h, TP_ERR_INVALID, "bad root %d", root);
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nw = (size_t)b->W * b->p.k, ns = (size_t)b->W;
+    const bool is_root = h->rank == root;
+    if (is_root) {
+        int rc = ensure(h, b->gather_w, sizeof(double) * nw * h->world);
+        if (rc == TP_OK) rc = ensure(h, b->gather_s, sizeof(int32_t) * ns * h->world);
+        if (rc != TP_OK) return rc;
+    }
+    hipEvent_t g0 = nullptr, g1 = nullptr;
+    HIP_TRY(h, hipEventCreate(&g0));
+    HIP_TRY(h, hipEventCreate(&g1));
+    HIP_TRY(h, hipEventRecord(g0, h->stream));
+    // one gather of the weights (and one of the statuses) to root, on the stream of the kernel
+    NCCL_TRY(h, ncclGroupStart());
+    NCCL_TRY(h, ncclGather(b->weights.p, is_root ? b->gather_w.p : nullptr, nw, ncclDouble, root, h->comm, h->stream));
+    NCCL_TRY(h, ncclGather(b->status.p, is_root ? b->gather_s.p : nullptr, ns, ncclInt32, root, h->comm, h->stream));
+    NCCL_TRY(h, ncclGroupEnd());
+    HIP_TRY(h, hipEventRecord(g1, h->stream));
+    HIP_TRY(h, hipEventSynchronize(g1));
+    float ms = 0;
+    HIP_TRY(h, hipEventElapsedTime(&ms, g0, g1));
+    h->gather_ms = ms;
+    (void)hipEventDestroy(g0);
+    (void)hipEventDestroy(g1);
+    int rc = harvest_kernel_time(h);
+    if (rc != TP_OK) return rc;
+    if (is_root) {
+        if (weights_all) HIP_TRY(h, hipMemcpyAsync(weights_all, b->gather_w.p, sizeof(double) * nw * h->world, hipMemcpyDeviceToHost, h->stream));
+        if (status_all) HIP_TRY(h, hipMemcpyAsync(status_all, b->gather_s.p, sizeof(int32_t) * ns * h->world, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return TP_OK;
+}
+
+}  // extern "C"
