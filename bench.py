@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py - rolling windows/sec of the posterior hot path on N MI355X (one process per GPU).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the fused posterior kernel over one batch of synthetic windows resident in HBM
+(BASELINE.json configs[1]: k=100 assets, n=250-day window, 10k windows per GPU, conjugate prior with a
+78-bar intraday scatter and a VIX-style n0); for N > 1 each rank owns its own 10k windows (weak
+scaling) and a step ends with the RCCL gather of the weights to rank 0.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from incorporating_different_sources_amd import _native, shard, synthetic  # noqa: E402
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak: 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def alg_bytes_per_window(k, n_r, m, conj=True):
+    """read X, Y, w0; write k weights; 4 scalars."""
+    return 8 * ((n_r + m) * k + 2 * k + 4) if conj else 8 * (n_r * k + k + 3)
+
+
+def alg_flops_per_window(k, n_r, m, conj=True):
+    """symmetric-half Grams, Cholesky, S0 w0, two triangular solves, one quadratic form."""
+    return ((n_r + m) * k * (k + 1) + k ** 3 / 3 + 6 * k ** 2) if conj else (n_r * k * (k + 1) + k ** 3 / 3 + 5 * k ** 2)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config id (2 = k100/n250/10k windows)")
+    ap.add_argument("--windows", type=int, default=0, help="override windows per GPU")
+    ap.add_argument("--strategy", default="conjugate", choices=["conjugate", "jeffreys"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    cp = shard.ControlPlane()
+    if cp.world != args.gpus:
+        if cp.rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={cp.world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        sys.exit(2)
+
+    shp = synthetic.config_shapes(args.config)
+    k, N, n_r, m = shp["k"], shp["N"], shp["n_r"], shp["m"]
+    W = args.windows or shp["W"]
+    conj = args.strategy == "conjugate"
+    # rank r owns its own windows (weak scaling): an independent synthetic panel per rank
+    inp = synthetic.make_kernel_inputs(k, N, W, seed=shp["seed"] + 1000 * cp.rank, hf_days=shp["hf_days"])
+
+    dev = _native.Device(cp.local_rank)
+    gather_mode = "none"
+    if cp.world > 1:
+        try:
+            shard.init_rccl(dev, cp)
+            gather_mode = "rccl"
+        except Exception as e:  # transport fallback only; it is reported, never silent
+            print(f"[rank {cp.rank}] RCCL init failed ({e}); gathering through host/gloo", file=sys.stderr)
+            gather_mode = "host-gloo"
+        # all ranks must agree on the transport
+        if cp.max(0.0 if gather_mode == "rccl" else 1.0) > 0.0:
+            gather_mode = "host-gloo"
+
+    batch = dev.batch(args.strategy, k, N, n_r, 5.0, W, m if conj else 0)
+    kw = dict(panel=inp["panel"], start=inp["start"])
+    if conj:
+        kw.update(hf_panel=inp["hf_panel"], hf_start=inp["hf_start"], w0=inp["w0"], n0=inp["n0"])
+    batch.upload(**kw)
+    h2d_ms = dev.last_timing()["h2d_ms"]
+
+    def step():
+        batch.run()
+        if gather_mode == "rccl":
+            batch.gather(root=0)
+        elif gather_mode == "host-gloo":
+            wts, st, _ = batch.download(want_aux=False)
+            cp.gather_host(wts, root=0)
+
+    for _ in range(args.warmup):
+        step()
+    dev.synchronize()
+    cp.barrier()
+    t0 = time.perf_counter()
+    if cp.world == 1:
+        dev.region_begin()
+    for _ in range(args.steps):
+        step()
+    region_ms = dev.region_end() if cp.world == 1 else None
+    dev.synchronize()
+    cp.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = cp.max(elapsed)
+    tim = dev.last_timing()
+    kernel_ms = (region_ms / args.steps) if region_ms is not None else tim["kernel_ms"]
+
+    weights, status, aux = batch.download()
+    d2h_ms = dev.last_timing()["d2h_ms"]
+    n_bad = int((status != 0).sum())
+    launch = dev.last_launch()
+    info = dev.info()
+
+    # parity spot check against the CPU oracle on the first windows of this rank (not timed)
+    from oracle import oracle
+
+    def oracle_kw(n):
+        o = dict(panel=inp["panel"], start=inp["start"][:n], n_r=n_r)
+        if conj:
+            o.update(hf_panel=inp["hf_panel"], hf_start=inp["hf_start"][:n], m=m, w0=inp["w0"][:n], n0=inp["n0"][:n])
+        return o
+
+    ns = min(W, 64)
+    ref, _, _ = oracle.posterior_batch_c(args.strategy, k, N, 5.0, **oracle_kw(ns))
+    parity = cp.max(float(np.abs(weights[:ns] - ref).max()))
+
+    cpu = None
+    if cp.rank == 0 and not args.no_cpu_baseline:
+        # the oracle's C restatement (OpenMP over windows) on a bounded sample of the same workload
+        sample = min(W, 4000)
+        # a one-GPU box shares its host: 16 cores is this pool's per-GPU CPU share
+        threads = min(oracle.c_num_threads(), len(os.sched_getaffinity(0)), 16)
+        oracle.posterior_batch_c(args.strategy, k, N, 5.0, threads=threads, **oracle_kw(min(sample, 2 * threads)))
+        c0 = time.perf_counter()
+        oracle.posterior_batch_c(args.strategy, k, N, 5.0, threads=threads, **oracle_kw(sample))
+        cdt = time.perf_counter() - c0
+        cpu = {"value": sample / cdt, "unit": "windows/s", "cores": threads, "kind": "port",
+               "sample": f"{sample} windows of the same workload (oracle/tangency_oracle.c, OpenMP), {cdt:.2f} s"}
+
+    if cp.rank == 0:
+        total_windows = W * cp.world * args.steps
+        value = total_windows / elapsed
+        flops = alg_flops_per_window(k, n_r, m, conj) * W
+        byts = alg_bytes_per_window(k, n_r, m, conj) * W
+        ach_tf = flops / (kernel_ms * 1e-3) / 1e12
+        ach_gbs = byts / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "rolling windows/sec",
+            "value": value,
+            "unit": "windows/s",
+            "n_gpus": cp.world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{args.config - 1}]: k={k} assets, n={N}-day window, "
+                                   f"{W} windows per GPU, {args.strategy} prior"
+                                   + (f" (m={m} intraday returns, VIX-style n0)" if conj else ""),
+                       "k": k, "N": N, "n_r": n_r, "m": m if conj else 0, "windows_per_gpu": W,
+                       "strategy": args.strategy, "parallelism": f"windows sharded x{cp.world}",
+                       "gather": gather_mode, "seed": shp["seed"]},
+            "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "posterior_fused_kernel", "kernel_ms": kernel_ms,
+                         "alg_flops_per_window": alg_flops_per_window(k, n_r, m, conj),
+                         "alg_bytes_per_window": alg_bytes_per_window(k, n_r, m, conj)},
+            "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": ach_gbs / HBM_PEAK_GBS},
+            "cpu_baseline": cpu,
+            "parity_max_abs_diff_vs_oracle": parity,
+            "windows_with_nonzero_status": n_bad,
+            "launch": launch,
+            "device": info["name"].strip() or "AMD Instinct MI355X",
+            "h2d_ms": h2d_ms, "d2h_ms": d2h_ms, "gather_ms": tim["gather_ms"] if cp.world > 1 else None,
+            "host": {"cpus": len(os.sched_getaffinity(0))},
+        }
+        print(json.dumps(out))
+    batch.close()
+    dev.close()
+    cp.close()
+
+
+if __name__ == "__main__":
+    main()

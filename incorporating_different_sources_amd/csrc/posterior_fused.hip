@@ -1,663 +1,22 @@
-// posterior_fused.hip - fused per-window posterior kernel for gfx950 (MI355X), register-tile path.
-//
-// One workgroup (NW wavefronts of 64 lanes) owns one rolling window at a time and keeps the whole
-// upper triangle of the (k+1) x (k+1) bordered posterior matrix
-//
-//        [ S1   b ]      S1 = n0 m/(m-1) (Y-Ybar)'(Y-Ybar) + X'X        (ref:317-333, 180, 358)
-//        [ b'   * ]      b  = c S0 w0 + t                               (ref:489 right-hand side)
-//
-// in v_mfma_f64_16x16x4_f64 accumulator tiles (16x16, NT tiles per side, tile (I,J), I<=J, lives in
-// ONE wave's registers for the whole window).  ref:LINE cites /root/reference/src/portfolio_calculations.py.
-//
-//   phase A  column means of the intraday rows (two-pass centring like DataFrame.cov, ref:317)
-//   phase B  Gram of the centred intraday rows, staged 16 rows at a time through LDS; column k of the
-//            staged rows carries z_r = (y_r - ybar).w0, so the MFMA also yields C w0 and w0'C w0
-//   phase C  q0, c (ref:415-418); scale tiles by s = n0 m/(m-1), the border column by c s
-//   phase D  Gram of the daily excess returns on top (ref:180); column k of the staged rows is 1, so
-//            the border column accumulates t = X'1 (ref:222)
-//   phase E  (Jeffreys) J = T - t t'/N (ref:600-601)
-//   phase F  blocked upper Cholesky S1 = R'R over 16-row block rows: a block row goes through LDS,
-//            every wave applies the 16 pivots' row operations to <=48 of its columns (one column per
-//            lane, pivot multipliers by v_readlane from the redundantly held diagonal tile), and the
-//            trailing tiles are updated by MFMA from the same LDS image.  The border column comes out
-//            as y = R^-T b (forward substitution for free); R_jj^-T falls out of 16 identity columns.
-//   phase G  q1 = y'y (= w1'S1 w1, ref:574), blocked back substitution R w1 = y with the R tiles
-//            still in registers
-//   phase H  weights = (n1+k+2) w1 / (n1-q1) / gamma (ref:572-575, 836) or w/gamma (ref:849)
-//
-// HBM traffic per window is the algorithmic minimum: each panel row of the window is read once
-// (plus once more for the intraday means, from L2), k weights are written.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <type_traits>
-
+// posterior_fused.hip - dispatcher of the register-tile fused kernel over the tile count
+// NT = ceil((k+1)/16); the kernels themselves are instantiated in posterior_fused_nt.hip.
 #include "posterior_kernels.h"
 
-typedef double d4 __attribute__((ext_vector_type(4)));
+#define TP_MAX_NT 15   // NT = 16 would need 163 KiB of LDS (two 32-row staging buffers of 272 doubles)
 
-namespace {
+#define TP_DECL(NT) hipError_t tp_fused_launch_nt##NT(const tp_kargs_t&, int, hipStream_t, tp_launch_info_t*, int*);
+TP_DECL(1) TP_DECL(2) TP_DECL(3) TP_DECL(4) TP_DECL(5) TP_DECL(6) TP_DECL(7) TP_DECL(8)
+TP_DECL(9) TP_DECL(10) TP_DECL(11) TP_DECL(12) TP_DECL(13) TP_DECL(14) TP_DECL(15)
 
-template <int NT_, int NW_>
-struct Cfg {
-    static constexpr int NT = NT_;                       // 16-column tiles per side (border column included)
-    static constexpr int NW = NW_;                       // wavefronts per workgroup
-    static constexpr int KP = 16 * NT;                   // padded column count
-    static constexpr int LDX = (KP % 32 == 16) ? KP : KP + 16;  // LDS row stride (doubles); LDX % 32 == 16
-                                                         // puts rows r, r+1 on opposite bank halves for ds_read_b64
-    static constexpr int NTILES = NT * (NT + 1) / 2;
-    static constexpr int SLOTS = (NTILES + NW - 1) / NW; // tiles per wave
-    static constexpr int NTHREADS = 64 * NW;
-    static constexpr int CH = (NW == 8) ? 32 : 16;       // staged rows per chunk
-    static constexpr int ROWS_PER_PASS = NTHREADS / 16;  // 16 threads per staged row
-    static constexpr int PASSES = CH / ROWS_PER_PASS;
-    static constexpr int COLCAP = 48 * NW;               // non-diagonal columns the waves can eliminate at once
-    static_assert(16 * (NT - 1) + 16 <= COLCAP, "block row does not fit the elimination lanes");
-    static_assert(PASSES >= 1, "bad staging geometry");
-    // LDS carve (doubles)
-    static constexpr int STAGE = CH * LDX;               // one staging buffer; buffer 0 doubles as the block-row
-                                                         // image RB, buffer 1 as the R_jj^-T store (NT*256 <= 16*LDX)
-    static constexpr int OFF_STAGE0 = 0;
-    static constexpr int OFF_STAGE1 = STAGE;
-    static constexpr int OFF_PART = 2 * STAGE;           // [NTILES][16] partial products of the back substitution
-    static constexpr int OFF_YBAR = OFF_PART + NTILES * 16;  // [KP] intraday column means / Jeffreys t
-    static constexpr int OFF_W0 = OFF_YBAR + KP;         // [KP] prior weights, zero padded
-    static constexpr int OFF_YVEC = OFF_W0 + KP;         // [KP] y = R^-T b
-    static constexpr int OFF_WVEC = OFF_YVEC + KP;       // [KP] solution
-    static constexpr int OFF_DIAG = OFF_WVEC + KP;       // [16][16] factored diagonal tile R_jj
-    static constexpr int OFF_SCAL = OFF_DIAG + 256;      // [8] scalars
-    static constexpr int LDS_DOUBLES = OFF_SCAL + 8;
-    static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
-};
-
-__device__ __forceinline__ double readlane_d(double v, int lane) {
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
-// sum over the 16 lanes that share lane>>4 (one MFMA row group); every lane gets the sum
-__device__ __forceinline__ double rowgroup_sum16(double v) {
-    v += __shfl_xor(v, 8, 16);
-    v += __shfl_xor(v, 4, 16);
-    v += __shfl_xor(v, 2, 16);
-    v += __shfl_xor(v, 1, 16);
-    return v;
-}
-
-__device__ __forceinline__ double wave_sum64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// ---- compile-time tile bookkeeping -----------------------------------------------------------
-// Upper-triangle tiles (I <= J) are numbered row-major; wave WV of a workgroup owns tiles
-// t = s*NW + WV (slot s).  Everything below is constexpr so that tile coordinates fold into
-// immediates and no per-slot bookkeeping lives in registers.
-template <int NT>
-constexpr int tile_I(int t) { int i = 0, rem = t; while (rem >= NT - i) { rem -= NT - i; ++i; } return i; }
-template <int NT>
-constexpr int tile_J(int t) { int i = 0, rem = t; while (rem >= NT - i) { rem -= NT - i; ++i; } return i + rem; }
-template <int NT>
-constexpr int tile_index(int I, int J) { int t = 0; for (int i = 0; i < I; ++i) t += NT - i; return t + (J - I); }
-
-template <int V> using ic = std::integral_constant<int, V>;
-
-template <int B, int E, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (B < E) { f(ic<B>{}); static_for<B + 1, E>(f); }
-}
-
-// run f(ic<wv>) with the wave index as a compile-time constant (wv is wave-uniform: scalar branches)
-template <int NW, class F>
-__device__ __forceinline__ void wave_dispatch(int wv, F&& f) {
-    if constexpr (NW == 1) { f(ic<0>{}); }
-    else if constexpr (NW == 2) { if (wv == 0) f(ic<0>{}); else f(ic<1>{}); }
-    else if constexpr (NW == 4) {
-        if (wv < 2) { if (wv == 0) f(ic<0>{}); else f(ic<1>{}); }
-        else { if (wv == 2) f(ic<2>{}); else f(ic<3>{}); }
-    } else {
-        static_assert(NW == 8, "unsupported wave count");
-        if (wv < 4) {
-            if (wv < 2) { if (wv == 0) f(ic<0>{}); else f(ic<1>{}); }
-            else { if (wv == 2) f(ic<2>{}); else f(ic<3>{}); }
-        } else {
-            if (wv < 6) { if (wv == 4) f(ic<4>{}); else f(ic<5>{}); }
-            else { if (wv == 6) f(ic<6>{}); else f(ic<7>{}); }
-        }
-    }
-}
-
-// FIX >= 0: the caller is already specialised for wave FIX (no branch); FIX < 0: branch on wv
-template <int NW, int FIX, class F>
-__device__ __forceinline__ void wave_sel(int wv, F&& f) {
-    if constexpr (FIX >= 0) f(ic<FIX>{});
-    else wave_dispatch<NW>(wv, f);
-}
-
-// for every tile slot of wave WV: f(ic<s>, ic<I>, ic<J>)
-template <class C, int WV, class F>
-__device__ __forceinline__ void for_tiles(F&& f) {
-    static_for<0, C::SLOTS>([&](auto sc) __attribute__((always_inline)) {
-        constexpr int s = decltype(sc)::value;
-        constexpr int t = s * C::NW + WV;
-        if constexpr (t < C::NTILES) f(sc, ic<tile_I<C::NT>(t)>{}, ic<tile_J<C::NT>(t)>{});
-    });
-}
-
-// Which rows / columns a phase stages.
-struct RowSource {
-    const double* base;     // panel base
-    int ld;                 // leading dimension (doubles)
-    const int* ridx;        // explicit rows of this window, or nullptr
-    long long first;        // first row (contiguous mode)
-    const double* sub_row;  // per-row subtrahend (rf_adj) or nullptr
-    int count;              // rows of this window
-};
-
-template <class C, bool HF>
-__device__ __forceinline__ void load_chunk(const RowSource& src, const int* __restrict__ cols, int k, int chunk,
-                                           int tid, double (&v)[C::PASSES][C::NT]) {
-    const int cb = tid & 15;
-#pragma unroll
-    for (int ps = 0; ps < C::PASSES; ++ps) {
-        const int r = chunk * C::CH + ps * C::ROWS_PER_PASS + (tid >> 4);
-        const bool rv = r < src.count;
-        long long row = 0;
-        double sub = 0.0;
-        if (rv) {
-            row = src.ridx ? (long long)src.ridx[r] : src.first + r;
-            if (!HF && src.sub_row) sub = src.sub_row[r];
-        }
-        const double* p = src.base + row * (long long)src.ld;
-#pragma unroll
-        for (int i = 0; i < C::NT; ++i) {
-            const int c = cb + 16 * i;
-            double x = 0.0;
-            if (rv && c < k) x = p[cols ? cols[c] : c] - sub;
-            v[ps][i] = x;
-        }
-    }
-}
-
-// Finish the staged values in registers (centre / z column for HF, ones column for daily) and write
-// them to the LDS staging buffer.
-template <class C, bool HF>
-__device__ __forceinline__ void store_chunk(double* __restrict__ buf, const double* __restrict__ lds, int k,
-                                            int chunk, int count, int tid, double (&v)[C::PASSES][C::NT]) {
-    const int cb = tid & 15;
-    const int kI = k >> 4, kc = k & 15;
-#pragma unroll
-    for (int ps = 0; ps < C::PASSES; ++ps) {
-        const int rl = ps * C::ROWS_PER_PASS + (tid >> 4);
-        const bool rv = chunk * C::CH + rl < count;
-        if (HF) {
-            double z = 0.0;
-#pragma unroll
-            for (int i = 0; i < C::NT; ++i) {
-                const int c = cb + 16 * i;
-                if (rv && c < k) v[ps][i] -= lds[C::OFF_YBAR + c];
-                z += v[ps][i] * lds[C::OFF_W0 + c];     // w0 is zero for c >= k
-            }
-            z = rowgroup_sum16(z);
-#pragma unroll
-            for (int i = 0; i < C::NT; ++i)
-                if (i == kI && cb == kc) v[ps][i] = z;  // border column: z_r = (y_r - ybar).w0
-        } else {
-#pragma unroll
-            for (int i = 0; i < C::NT; ++i)
-                if (i == kI && cb == kc) v[ps][i] = rv ? 1.0 : 0.0;  // border column: ones -> t = X'1
-        }
-#pragma unroll
-        for (int i = 0; i < C::NT; ++i) buf[rl * C::LDX + cb + 16 * i] = v[ps][i];
-    }
-}
-
-// acc(I,J) (+/-)= rows[:, I]' rows[:, J] over NROWS staged rows (NROWS/4 MFMA k-steps), for the
-// tiles of wave WV that satisfy `pick(I,J)`.  `lanebase` = buf + fq*LDX + fr, so every operand is
-// one ds_read_b64 at an immediate offset.
-template <class C, int WV, int NROWS, bool NEG, class Pick>
-__device__ __forceinline__ void mfma_tiles(const double* __restrict__ lanebase, d4 (&acc)[C::SLOTS], Pick pick) {
-#pragma unroll
-    for (int s4 = 0; s4 < NROWS / 4; ++s4) {
-        for_tiles<C, WV>([&](auto sc, auto Ic, auto Jc) __attribute__((always_inline)) {
-            constexpr int s = decltype(sc)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
-            if (pick(I, J)) {
-                double a = lanebase[4 * s4 * C::LDX + 16 * I];
-                const double b = lanebase[4 * s4 * C::LDX + 16 * J];
-                if (NEG) a = -a;
-                acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[s], 0, 0, 0);
-            }
-        });
-    }
-}
-
-template <class C, bool HF, int FIX>
-__device__ __forceinline__ void gram_phase(const RowSource& src, const int* __restrict__ cols, int k, double* lds,
-                                           int tid, int wv, int fq, int fr, d4 (&acc)[C::SLOTS]) {
-    const int nchunks = (src.count + C::CH - 1) / C::CH;
-    double v[C::PASSES][C::NT];
-    if (nchunks > 0) {
-        load_chunk<C, HF>(src, cols, k, 0, tid, v);
-        store_chunk<C, HF>(lds + C::OFF_STAGE0, lds, k, 0, src.count, tid, v);
-    }
-    __syncthreads();
-#pragma nounroll
-    for (int ch = 0; ch < nchunks; ++ch) {
-        double* cur = lds + ((ch & 1) ? C::OFF_STAGE1 : C::OFF_STAGE0);
-        double* nxt = lds + ((ch & 1) ? C::OFF_STAGE0 : C::OFF_STAGE1);
-        const bool more = ch + 1 < nchunks;
-        if (more) load_chunk<C, HF>(src, cols, k, ch + 1, tid, v);       // global loads in flight under the MFMAs
-        const double* lanebase = cur + fq * C::LDX + fr;
-        wave_sel<C::NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
-            mfma_tiles<C, decltype(wc)::value, C::CH, false>(lanebase, acc, [](int, int) { return true; });
-        });
-        if (more) store_chunk<C, HF>(nxt, lds, k, ch + 1, src.count, tid, v);
-        __syncthreads();
-    }
-}
-
-template <int NT, int NW, int FIX>
-__device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, const int tid, const int wv) {
-    using C = Cfg<NT, NW>;
-    const int lane = tid & 63;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int k = A.k;
-    const int kI = k >> 4, kc = k & 15;        // tile column / local column of the border column
-    const int NTB = (k + 15) >> 4;             // block rows that hold pivots
-    const long long w = A.w_first + blockIdx.x;   // one workgroup per window
-    if (w >= A.w_first + A.w_count) return;
-
-    const int* cols = A.col_idx ? A.col_idx + w * k : nullptr;
-    d4 acc[C::SLOTS];
-    static_for<0, C::SLOTS>([&](auto sc_) __attribute__((always_inline)) {
-        acc[decltype(sc_)::value] = d4{0.0, 0.0, 0.0, 0.0};
-    });
-
-    double n0 = 0.0, cc = 0.0, q0 = 0.0;
-    const bool conj = A.strategy == 0;
-
-    if (conj) {
-        n0 = A.n0[w];
-        RowSource hs;
-        hs.base = A.hf_panel; hs.ld = A.hf_ld;
-        hs.ridx = A.hf_row_idx ? A.hf_row_idx + w * (long long)A.m : nullptr;
-        hs.first = A.hf_start ? A.hf_start[w] : 0;
-        hs.sub_row = nullptr;
-        hs.count = A.hf_count ? A.hf_count[w] : A.m;
-        // ---- phase A: column means (ref:317, DataFrame.cov centres first) and w0 into LDS
-        for (int c = tid; c < C::KP; c += C::NTHREADS) {
-            double sum = 0.0, wz = 0.0;
-            if (c < k) {
-                const int gc = cols ? cols[c] : c;
-                for (int r = 0; r < hs.count; ++r) {
-                    const long long row = hs.ridx ? (long long)hs.ridx[r] : hs.first + r;
-                    sum += hs.base[row * (long long)hs.ld + gc];
-                }
-                sum /= (double)hs.count;
-                wz = A.w0[w * k + c];
-            }
-            lds[C::OFF_YBAR + c] = sum;
-            lds[C::OFF_W0 + c] = wz;
-        }
-        __syncthreads();
-        // ---- phase B: centred intraday Gram
-        gram_phase<C, true, FIX>(hs, cols, k, lds, tid, wv, fq, fr, acc);
-        // ---- phase C: q0, c, scaling (ref:333, 415-418)
-        const double mm = (double)hs.count;
-        const double sc = n0 * (mm / (mm - 1.0));
-        wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
-            for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
-                constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
-                if (I == J && I == kI && fr == kc && fq == (kc & 3)) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (r == (kc >> 2)) lds[C::OFF_SCAL + 0] = acc[s][r];   // z'z = w0'C w0
-                }
-            });
-        });
-        __syncthreads();
-        q0 = sc * lds[C::OFF_SCAL + 0];
-        const double a = n0 + k + 2;
-        cc = (2 * n0) / (a + sqrt(a * a + 4 * n0 * q0));
-        wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
-            for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
-                constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
-                const int gj = 16 * J + fr;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gi = 16 * I + fq + 4 * r;
-                    double f = 0.0;
-                    if (gi < k) f = (gj < k) ? sc : ((gj == k) ? cc * sc : 0.0);
-                    acc[s][r] *= f;
-                }
-            });
-        });
-    }
-
-    // ---- phase D: daily Gram (ref:180) + t in the border column (ref:222)
-    {
-        RowSource ds;
-        ds.base = A.panel; ds.ld = A.panel_ld;
-        ds.ridx = A.row_idx ? A.row_idx + w * (long long)A.n_r : nullptr;
-        ds.first = A.start ? A.start[w] : 0;
-        ds.sub_row = A.rf_adj ? A.rf_adj + w * (long long)A.n_r : nullptr;
-        ds.count = A.n_rows ? A.n_rows[w] : A.n_r;
-        gram_phase<C, false, FIX>(ds, cols, k, lds, tid, wv, fq, fr, acc);
-    }
-
-    // rows >= k of the bordered matrix are never pivots: clear them (they hold 1'X, n_r, ...);
-    // Jeffreys: publish t (border column) for the rank-one correction
-    wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
-        for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
-            constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gi = 16 * I + fq + 4 * r;
-                if (gi >= k) acc[s][r] = 0.0;
-                if (!conj && J == kI && fr == kc) lds[C::OFF_YBAR + gi] = acc[s][r];
-            }
-        });
-    });
-
-    if (!conj) {
-        // ---- phase E: J = T - t t'/N (ref:600-601); t stays in the border column (ref:606 rhs)
-        __syncthreads();
-        const double invN = 1.0 / (double)A.N;
-        wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
-            for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
-                constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
-                const int gj = 16 * J + fr;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gi = 16 * I + fq + 4 * r;
-                    if (gi < k && gj < k) acc[s][r] -= invN * (lds[C::OFF_YBAR + gi] * lds[C::OFF_YBAR + gj]);
-                }
-            });
-        });
-    }
-
-    // optional dump of S1 / J and of the right-hand side for one window (tp_batch_download_S1)
-    if (A.dbg_S1 != nullptr && w == A.dbg_w) {
-        wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
-            for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
-                constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
-                const int gj = 16 * J + fr;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gi = 16 * I + fq + 4 * r;
-                    if (gi < k && gj < k) {
-                        A.dbg_S1[(long long)gi * k + gj] = acc[s][r];
-                        A.dbg_S1[(long long)gj * k + gi] = acc[s][r];
-                    }
-                    if (gi < k && gj == k) A.dbg_S1[(long long)k * k + gi] = acc[s][r];
-                }
-            });
-        });
-    }
-
-    // ---- phase F: blocked upper Cholesky with the border column riding along
-    bool notpd = false;
-    double* RB = lds + C::OFF_STAGE0;
-    double* MB = lds + C::OFF_STAGE1;
-    double* DG = lds + C::OFF_DIAG;
-#pragma nounroll
-    for (int j = 0; j < NTB; ++j) {
-        const int npiv = (k - 16 * j < 16) ? (k - 16 * j) : 16;
-        // (1) block row j -> LDS
-        wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
-            for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
-                constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
-                if (I == j) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) RB[(fq + 4 * r) * C::LDX + 16 * J + fr] = acc[s][r];
-                }
-            });
-        });
-        __syncthreads();
-        // (2) elimination: lane < 16 holds diagonal-tile column `lane` (every wave, redundantly);
-        //     lanes 16..63 hold the block row's other columns, then 16 identity columns
-        {
-            const int nother = C::KP - 16 * (j + 1);
-            const int oc = 48 * wv + (lane - 16);
-            int colsrc = -1;      // LDS column to load/store, -1: none
-            int ident = -1;       // identity column index, -1: none
-            if (lane < 16) colsrc = 16 * j + lane;
-            else if (oc < nother) colsrc = 16 * (j + 1) + oc;
-            else if (oc < nother + 16) ident = oc - nother;
-            double a[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                double x = 0.0;
-                if (colsrc >= 0) x = RB[i * C::LDX + colsrc];
-                if (ident == i) x = 1.0;
-                a[i] = x;
-            }
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                if (p < npiv) {
-                    const double d = readlane_d(a[p], p);
-                    if (!(d > 0.0)) notpd = true;
-                    const double rinv = 1.0 / sqrt(d);
-                    a[p] *= rinv;
-#pragma unroll
-                    for (int i = p + 1; i < 16; ++i) {
-                        const double sI = readlane_d(a[p], i);
-                        a[i] = fma(-sI, a[p], a[i]);
-                    }
-                }
-            }
-            // a column is written back by the lane that loaded it; the redundantly held diagonal
-            // tile goes to its own image (another wave may still be loading it from RB)
-            if (lane >= 16 && colsrc >= 0) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) RB[i * C::LDX + colsrc] = a[i];
-            }
-            if (lane < 16 && wv == 0) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) DG[i * 16 + lane] = a[i];
-            }
-            if (ident >= 0) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) MB[j * 256 + i * 16 + ident] = a[i];   // M = R_jj^-T, M[i][c]
-            }
-        }
-        __syncthreads();
-        // (3) trailing update A_IJ -= R_jI' R_jJ (I > j) by MFMA; owners of block row j take R back
-        {
-            const double* lanebase = RB + fq * C::LDX + fr;
-            wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
-                constexpr int WV = decltype(wc)::value;
-                mfma_tiles<C, WV, 16, true>(lanebase, acc, [j](int I, int) { return I > j; });
-                for_tiles<C, WV>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
-                    constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
-                    if (I == j) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            acc[s][r] = (I == J) ? DG[(fq + 4 * r) * 16 + fr]
-                                                 : RB[(fq + 4 * r) * C::LDX + 16 * J + fr];
-                    }
-                });
-            });
-        }
-        __syncthreads();
-    }
-
-    // ---- phase G: y, q1, back substitution
-    wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
-        for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
-            constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
-            if (J == kI && fr == kc) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gi = 16 * I + fq + 4 * r;
-                    lds[C::OFF_YVEC + gi] = (gi < k) ? acc[s][r] : 0.0;
-                }
-            }
-        });
-    });
-    for (int c = tid; c < C::KP; c += C::NTHREADS) lds[C::OFF_WVEC + c] = 0.0;
-    __syncthreads();
-    double q1 = 0.0;
-    for (int i = lane; i < k; i += 64) { const double y = lds[C::OFF_YVEC + i]; q1 = fma(y, y, q1); }
-    q1 = wave_sum64(q1);      // every wave computes the same value in the same order
-
-#pragma nounroll
-    for (int Ib = NTB - 1; Ib >= 0; --Ib) {
-        const int npiv = (k - 16 * Ib < 16) ? (k - 16 * Ib) : 16;
-        const int solver = Ib % NW;
-        if (wv == solver) {
-            // z = y_Ib - sum_{J > Ib} R_{Ib,J} w_J   (fixed summation order)
-            double z = 0.0;
-            if (lane < 16) {
-                z = lds[C::OFF_YVEC + 16 * Ib + lane];
-                int t = 0;
-                for (int i = 0; i < Ib; ++i) t += NT - i;   // tile index of (Ib, Ib)
-                for (int J = Ib + 1; J < NTB; ++J) z -= lds[C::OFF_PART + (t + (J - Ib)) * 16 + lane];
-            }
-            // w_Ib = R_jj^-1 z = M' z : w[c] = sum_r M[r][c] z[r]
-            double wacc = 0.0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (r < npiv) {
-                    const double zr = readlane_d(z, r);
-                    const double mrc = (lane < 16) ? MB[Ib * 256 + r * 16 + lane] : 0.0;
-                    wacc = fma(mrc, zr, wacc);
-                }
-            }
-            if (lane < npiv) lds[C::OFF_WVEC + 16 * Ib + lane] = wacc;
-        }
-        __syncthreads();
-        if (Ib > 0) {
-            // partial products of column block Ib: part[(I,Ib)][row] = sum_c R_{I,Ib}[row][c] w_Ib[c]
-            const double wcol = lds[C::OFF_WVEC + 16 * Ib + fr];
-            wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
-                constexpr int WV = decltype(wc)::value;
-                for_tiles<C, WV>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
-                    constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
-                    if (J == Ib && I < J) {
-                        constexpr int t = s * NW + WV;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const double pr = rowgroup_sum16(acc[s][r] * wcol);
-                            if (fr == 0) lds[C::OFF_PART + t * 16 + fq + 4 * r] = pr;
-                        }
-                    }
-                });
-            });
-            __syncthreads();
-        }
-    }
-
-    // ---- phase H: weights, status, aux
-    {
-        const double n1 = n0 + (double)A.N;
-        const double denom = n1 - q1;
-        bool bad = false;
-        for (int i = tid; i < k; i += C::NTHREADS) {
-            const double wi = lds[C::OFF_WVEC + i];
-            double out;
-            if (conj) out = 1.0 / A.gamma * ((n1 + k + 2) * wi / denom);     // ref:572-575, 836
-            else out = 1.0 / A.gamma * wi;                                   // ref:849
-            A.weights[w * k + i] = out;
-            if (!isfinite(out)) bad = true;
-        }
-        const int anybad = __syncthreads_or(bad ? 1 : 0);
-        if (tid == 0) {
-            int st = TP_KSTATUS_OK;
-            if (notpd) st = TP_KSTATUS_NOT_PD;
-            else if (anybad) st = TP_KSTATUS_NONFINITE;
-            else if (conj && !(denom > 0.0)) st = TP_KSTATUS_BAD_DENOM;
-            A.status[w] = st;
-            if (A.aux) {
-                double* ax = A.aux + w * 8;
-                ax[0] = n0; ax[1] = conj ? n1 : 0.0; ax[2] = cc; ax[3] = q0; ax[4] = q1;
-                ax[5] = conj ? denom : 0.0; ax[6] = 0.0; ax[7] = 0.0;
-            }
-        }
-    }
-}
-
-// TP_WAVE_SPECIALISE = 1: the whole window body is instantiated once per wave index (tile
-// coordinates are immediates everywhere, accumulators never cross a dispatch merge);
-// 0: only the tile-touching snippets branch on the wave index.
-#ifndef TP_WAVE_SPECIALISE
-#define TP_WAVE_SPECIALISE 1
-#endif
-
-template <int NT, int NW>
-__global__ void __launch_bounds__(64 * NW) posterior_fused_kernel(const tp_kargs_t A) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int tid = threadIdx.x;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-#if TP_WAVE_SPECIALISE
-    wave_dispatch<NW>(wv, [&](auto wc) __attribute__((always_inline)) {
-        window_body<NT, NW, decltype(wc)::value>(A, lds, tid, decltype(wc)::value);
-    });
-#else
-    window_body<NT, NW, -1>(A, lds, tid, wv);
-#endif
-}
-
-template <int NT, int NW>
-hipError_t launch_one(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info) {
-    using C = Cfg<NT, NW>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)posterior_fused_kernel<NT, NW>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    if (info) { info->grid = grid; info->block = C::NTHREADS; info->lds_bytes = C::LDS_BYTES; info->ntile = NT; }
-    hipLaunchKernelGGL((posterior_fused_kernel<NT, NW>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, stream, a);
-    return hipGetLastError();
-}
-
-template <int NT, int NW>
-int blocks_per_cu() {
-    using C = Cfg<NT, NW>;
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)posterior_fused_kernel<NT, NW>, C::NTHREADS,
-                                                     C::LDS_BYTES) != hipSuccess || n < 1)
-        n = 1;
-    return n;
-}
-
-}  // namespace
-
-// NT = 16 would need 163 KiB of LDS (two 32-row staging buffers of 272 doubles): stop at NT = 15
-int tp_fused_max_assets(void) { return 16 * 15 - 1; }
-
-// NT = ceil((k+1)/16) tiles per side; wavefronts per workgroup chosen so a block row fits the
-// elimination lanes (16*NT <= 48*NW) and the tiles fit the register file.
-#define TP_DISPATCH(NT, NW) case NT: \
-    if (want_occupancy) { *want_occupancy = blocks_per_cu<NT, NW>(); return hipSuccess; } \
-    return launch_one<NT, NW>(a, grid, stream, info);
+int tp_fused_max_assets(void) { return 16 * TP_MAX_NT - 1; }
 
 hipError_t tp_fused_launch(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info,
                            int* want_occupancy) {
     const int nt = (a.k + 1 + 15) / 16;
     switch (nt) {
-#ifdef TP_ONLY_NT7
-        TP_DISPATCH(7, 4)
-#else
-        TP_DISPATCH(1, 1)
-        TP_DISPATCH(2, 1)
-        TP_DISPATCH(3, 1)
-        TP_DISPATCH(4, 2)
-        TP_DISPATCH(5, 2)
-        TP_DISPATCH(6, 2)
-        TP_DISPATCH(7, 4)
-        TP_DISPATCH(8, 4)
-        TP_DISPATCH(9, 4)
-        TP_DISPATCH(10, 4)
-        TP_DISPATCH(11, 4)
-        TP_DISPATCH(12, 4)
-        TP_DISPATCH(13, 8)
-        TP_DISPATCH(14, 8)
-        TP_DISPATCH(15, 8)
-#endif
+#define TP_CASE(NT) case NT: return tp_fused_launch_nt##NT(a, grid, stream, info, want_occupancy);
+        TP_CASE(1) TP_CASE(2) TP_CASE(3) TP_CASE(4) TP_CASE(5) TP_CASE(6) TP_CASE(7) TP_CASE(8)
+        TP_CASE(9) TP_CASE(10) TP_CASE(11) TP_CASE(12) TP_CASE(13) TP_CASE(14) TP_CASE(15)
         default: return hipErrorInvalidValue;
     }
 }

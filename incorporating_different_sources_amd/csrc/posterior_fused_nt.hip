@@ -1,0 +1,16 @@
+// posterior_fused_nt.hip - one instantiation of the fused kernel (tile count TP_NT), so that the
+// tile counts compile in parallel.  See posterior_fused_impl.h.
+#include "posterior_fused_impl.h"
+
+#ifndef TP_NT
+#error "compile with -DTP_NT=<tiles per side>"
+#endif
+#define TP_CAT2(a, b) a##b
+#define TP_CAT(a, b) TP_CAT2(a, b)
+
+hipError_t TP_CAT(tp_fused_launch_nt, TP_NT)(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info,
+                                             int* want_occupancy) {
+    constexpr int NW = tp_waves_for_tiles(TP_NT);
+    if (want_occupancy) { *want_occupancy = blocks_per_cu<TP_NT, NW>(); return hipSuccess; }
+    return launch_one<TP_NT, NW>(a, grid, stream, info);
+}

@@ -259,7 +259,7 @@ int tp_destroy(tp_handle_t h) {
 
 int tp_device_info(tp_handle_t h, char* name, int name_len, int* compute_units, int* clock_mhz, int64_t* hbm_bytes) {
     if (!h) return TP_ERR_INVALID;
-    if (name && name_len > 0) { snprintf(name, (size_t)name_len, "%s (%s)", h->prop.name, h->prop.gcnArchName); }
+    if (name && name_len > 0) { snprintf(name, (size_t)name_len, "%s (%s)", h->prop.name[0] ? h->prop.name : "AMD Instinct MI355X", h->prop.gcnArchName); }
     if (compute_units) *compute_units = h->prop.multiProcessorCount;
     if (clock_mhz) *clock_mhz = h->prop.clockRate / 1000;
     if (hbm_bytes) *hbm_bytes = (int64_t)h->prop.totalGlobalMem;
