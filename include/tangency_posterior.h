@@ -115,6 +115,12 @@ int tp_batch_download(tp_batch_t b, double* weights /* [W x k] */, int32_t* stat
                       double* aux /* optional [W x TP_AUX_STRIDE] */); /* waits for the stream, D2H */
 int tp_batch_download_S1(tp_batch_t b, int64_t w, double* S1 /* [k x k] */); /* posterior scale matrix
                       S1 (ref:358) / Jeffreys J (ref:600) of window w, recomputed by a debug launch */
+/* Read back one window's k x k matrix (symmetric, full storage) and its k-vector, recomputed by a
+ * one-window launch; `rhs` may be NULL.  The reference's same-named helper functions bind these. */
+#define TP_MATRIX_PRIOR 1      /* S0 (ref:285-333)            and c S0 w0                     */
+#define TP_MATRIX_GRAM 2       /* T  (ref:163-204)            and t (ref:206-245)             */
+#define TP_MATRIX_POSTERIOR 3  /* S1 (ref:358) / J (ref:600)  and c S0 w0 + t (ref:489) / t   */
+int tp_batch_download_matrix(tp_batch_t b, int64_t w, int what, double* M /* [k x k] */, double* rhs /* [k] */);
 int tp_batch_destroy(tp_batch_t b);
 
 /* One-shot convenience: upload + run + download.  Replaces

@@ -29,7 +29,7 @@ UNIQUE_ID_BYTES = 128
 # every symbol include/tangency_posterior.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTS = [
     "tp_version", "tp_max_assets", "tp_create", "tp_destroy", "tp_last_error", "tp_device_info",
-    "tp_batch_create", "tp_batch_upload", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1",
+    "tp_batch_create", "tp_batch_upload", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1", "tp_batch_download_matrix",
     "tp_batch_destroy", "tp_posterior_batch", "tp_synchronize", "tp_last_timing", "tp_region_begin",
     "tp_region_end", "tp_last_launch", "tp_comm_unique_id", "tp_comm_init", "tp_comm_destroy",
     "tp_batch_gather",
@@ -74,6 +74,7 @@ def _load():
     lib.tp_batch_run.argtypes = [c_void_p]
     lib.tp_batch_download.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int32), POINTER(c_double)]
     lib.tp_batch_download_S1.argtypes = [c_void_p, c_int64, POINTER(c_double)]
+    lib.tp_batch_download_matrix.argtypes = [c_void_p, c_int64, c_int, POINTER(c_double), POINTER(c_double)]
     lib.tp_batch_destroy.argtypes = [c_void_p]
     lib.tp_posterior_batch.argtypes = [c_void_p, POINTER(tp_params_t), c_int64, POINTER(tp_inputs_t),
                                        POINTER(c_double), POINTER(c_int32), POINTER(c_double)]
@@ -263,6 +264,15 @@ class Batch:
         S1 = np.empty((self.k, self.k), dtype=np.float64)
         self.dev._check(lib.tp_batch_download_S1(self._b, int(w), _ptr(S1, c_double)))
         return S1
+
+    def download_matrix(self, w: int, what):
+        """(M [k x k], rhs [k]) of window w: what = 'prior' (S0, c S0 w0), 'gram' (T, t) or
+        'posterior' (S1 or J, right-hand side)."""
+        code = {"prior": 1, "gram": 2, "posterior": 3}.get(what, what)
+        M = np.empty((self.k, self.k), dtype=np.float64)
+        rhs = np.empty(self.k, dtype=np.float64)
+        self.dev._check(lib.tp_batch_download_matrix(self._b, int(w), int(code), _ptr(M, c_double), _ptr(rhs, c_double)))
+        return M, rhs
 
     def gather(self, root=0):
         """One RCCL gather of every rank's [W x k] weights (and statuses) to `root`."""

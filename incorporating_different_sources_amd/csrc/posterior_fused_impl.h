@@ -279,8 +279,30 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
 
     double n0 = 0.0, cc = 0.0, q0 = 0.0;
     const bool conj = A.strategy == 0;
+    // debug read-back of one window's matrix (tp_batch_download_matrix): 1 = prior scatter S0 and
+    // c S0 w0, 2 = canonical statistics T and t only, 3 = posterior S1 (or Jeffreys J) and rhs
+    const int dbg = (A.dbg_S1 != nullptr && w == A.dbg_w) ? A.dbg_mode : 0;
 
-    if (conj) {
+    // dump the current bordered matrix: [k x k] symmetric part, then the border column
+    auto dump_matrix = [&]() __attribute__((always_inline)) {
+        wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
+            for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
+                constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
+                const int gj = 16 * J + fr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = 16 * I + fq + 4 * r;
+                    if (gi < k && gj < k) {
+                        A.dbg_S1[(long long)gi * k + gj] = acc[s][r];
+                        A.dbg_S1[(long long)gj * k + gi] = acc[s][r];
+                    }
+                    if (gi < k && gj == k) A.dbg_S1[(long long)k * k + gi] = acc[s][r];
+                }
+            });
+        });
+    };
+
+    if (conj && dbg != 2) {
         n0 = A.n0[w];
         RowSource hs;
         hs.base = A.hf_panel; hs.ld = A.hf_ld;
@@ -336,6 +358,7 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
                 }
             });
         });
+        if (dbg == 1) { dump_matrix(); return; }
     }
 
     // ---- phase D: daily Gram (ref:180) + t in the border column (ref:222)
@@ -362,6 +385,7 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
             }
         });
     });
+    if (dbg == 2) { dump_matrix(); return; }
 
     if (!conj) {
         // ---- phase E: J = T - t t'/N (ref:600-601); t stays in the border column (ref:606 rhs)
@@ -380,24 +404,7 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
         });
     }
 
-    // optional dump of S1 / J and of the right-hand side for one window (tp_batch_download_S1)
-    if (A.dbg_S1 != nullptr && w == A.dbg_w) {
-        wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
-            for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
-                constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
-                const int gj = 16 * J + fr;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gi = 16 * I + fq + 4 * r;
-                    if (gi < k && gj < k) {
-                        A.dbg_S1[(long long)gi * k + gj] = acc[s][r];
-                        A.dbg_S1[(long long)gj * k + gi] = acc[s][r];
-                    }
-                    if (gi < k && gj == k) A.dbg_S1[(long long)k * k + gi] = acc[s][r];
-                }
-            });
-        });
-    }
+    if (dbg == 3) dump_matrix();
 
     // ---- phase F: blocked upper Cholesky with the border column riding along
     bool notpd = false;

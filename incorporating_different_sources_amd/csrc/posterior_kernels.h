@@ -27,6 +27,7 @@ struct tp_kargs_t {
     double* aux;
     double* dbg_S1;       // optional [k*k + k]: S1 (or J) and the right-hand side of window dbg_w
     long long dbg_w;
+    int dbg_mode;         // 1 prior (S0 | c S0 w0), 2 canonical statistics (T | t), 3 posterior (S1 or J | rhs)
     long long w_first, w_count;
     int panel_ld, hf_ld;
     int k, N, n_r, m, strategy;

@@ -379,11 +379,14 @@ int tp_batch_download(tp_batch_t b, double* weights, int32_t* status, double* au
     return TP_OK;
 }
 
-int tp_batch_download_S1(tp_batch_t b, int64_t w, double* S1) {
-    if (!b || !S1) return TP_ERR_INVALID;
+int tp_batch_download_matrix(tp_batch_t b, int64_t w, int what, double* M, double* rhs) {
+    if (!b || !M) return TP_ERR_INVALID;
     tp_handle_t h = b->h;
-    if (!b->uploaded) return fail(h, TP_ERR_INVALID, "tp_batch_download_S1 before tp_batch_upload");
+    if (!b->uploaded) return fail(h, TP_ERR_INVALID, "tp_batch_download_matrix before tp_batch_upload");
     if (w < 0 || w >= b->W) return fail(h, TP_ERR_INVALID, "window %lld out of range", (long long)w);
+    if (what < TP_MATRIX_PRIOR || what > TP_MATRIX_POSTERIOR) return fail(h, TP_ERR_INVALID, "unknown matrix id %d", what);
+    if (what == TP_MATRIX_PRIOR && b->p.strategy != TP_STRATEGY_CONJUGATE)
+        return fail(h, TP_ERR_INVALID, "the prior scatter exists for the conjugate strategy only");
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t kk = (size_t)b->p.k * b->p.k;
     int rc = ensure(h, b->dbg, sizeof(double) * (kk + b->p.k));
@@ -391,16 +394,23 @@ int tp_batch_download_S1(tp_batch_t b, int64_t w, double* S1) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     rc = harvest_kernel_time(h);
     if (rc != TP_OK) return rc;
+    HIP_TRY(h, hipMemsetAsync(b->dbg.p, 0, sizeof(double) * (kk + b->p.k), h->stream));
     tp_kargs_t a = make_kargs(b);
     a.dbg_S1 = (double*)b->dbg.p;
     a.dbg_w = w;
+    a.dbg_mode = what;
     a.w_first = w;
     a.w_count = 1;
     rc = launch(b, a, 1, false);
     if (rc != TP_OK) return rc;
-    HIP_TRY(h, hipMemcpyAsync(S1, b->dbg.p, sizeof(double) * kk, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(M, b->dbg.p, sizeof(double) * kk, hipMemcpyDeviceToHost, h->stream));
+    if (rhs) HIP_TRY(h, hipMemcpyAsync(rhs, (double*)b->dbg.p + kk, sizeof(double) * b->p.k, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return TP_OK;
+}
+
+int tp_batch_download_S1(tp_batch_t b, int64_t w, double* S1) {
+    return tp_batch_download_matrix(b, w, TP_MATRIX_POSTERIOR, S1, nullptr);
 }
 
 int tp_posterior_batch(tp_handle_t h, const tp_params_t* p, int64_t W, const tp_inputs_t* in, double* weights,

@@ -1,0 +1,746 @@
+"""Backtest engine and Bayesian weight estimators with the reference's call surface
+(`/root/reference/src/portfolio_calculations.py`, cited below as ref:LINE), MI355X-native underneath.
+
+What is different from the reference is WHERE the arithmetic runs and HOW OFTEN the host touches
+pandas:
+
+* every rebalancing date of a backtest is known up front (the schedule depends only on the date list,
+  ref:1166-1176), so `backtest_portfolio` extracts all windows first, sends them to the GPU in ONE
+  batched call (`_native.posterior_batch` -> `libtangency.so`, include/tangency_posterior.h) and then
+  replays the cheap sequential P&L loop (ref:1127-1219) with the weights already in hand;
+* the per-window statistics (T, t, S0, c, S1, w1, q1, nu: ref:163-608) never exist on the host: the
+  fused HIP kernel produces the weights directly.  The same-named helper functions below exist for
+  API compatibility and run a one-window batch on the device.
+
+There is no CPU fallback for the estimators: without `libtangency.so` and a gfx950 GPU they raise.
+The passive weightings (vw / ew, ref:661-701) are host-side, as they are inputs (prior weights w0 and
+the comparison portfolio), not part of the accelerated path.  Shrinkage, Black-Litterman, Jorion and
+Greyserman (ref:703-817, 851-938) are outside the scope of this build and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from datetime import timedelta
+
+import numpy as np
+import pandas as pd
+
+try:  # importable both as a package module and as a top-level `portfolio_calculations` (main.py style)
+    from . import _native
+except ImportError:  # pragma: no cover - top-level import with the package directory on sys.path
+    import _native  # type: ignore
+
+logging_level = os.environ.get("LOGGING_LEVEL", logging.INFO)
+logging.basicConfig(level=logging_level)
+logger = logging.getLogger(__name__)
+
+# The reference's CHECK flag (ref:30) switches on O(n k^2) Python self-consistency loops; the
+# identities they test are covered by tests/ here, so the flag defaults to off and only enables the
+# cheap algebraic checks (ref:81-86, 420-428) on values returned by the device.
+CHECK = False
+
+_CONJUGATE = ("conjugate_hf_vix_vw", "conjugate_hf_vix_ew", "conjugate_hf_epu_vw", "conjugate_hf_epu_ew")
+_OUT_OF_SCOPE = ("shrinkage", "black_litterman", "jorion", "greyserman")
+_RESAMPLE_RULE = {"weekly": "W", "monthly": "ME"}
+
+
+# ======================================================================================================
+# small frequency tables (ref:116-134, 299-308, 628-637)
+def get_window_annualization_factor(portfolio_spec):
+    return {"daily": 252, "weekly": 52, "monthly": 12}[portfolio_spec["rolling_window_frequency"]]
+
+
+def get_window_trading_days(portfolio_spec):
+    per_period = {"daily": 1, "weekly": 5, "monthly": 22}[portfolio_spec["rolling_window_frequency"]]
+    return portfolio_spec["rolling_window"] * per_period
+
+
+def _calendar_days_of(frequency):
+    try:
+        return {"daily": 1, "weekly": 7, "monthly": 31}[frequency]
+    except KeyError:
+        logger.error("Unknown rolling window frequency.")
+        raise RuntimeError("Unknown rolling window frequency.")
+
+
+def _resample_last(df, frequency):
+    """ref:149-156 / ref:102-109: last observation per calendar week / month ('daily' = unchanged)."""
+    if frequency == "daily":
+        return df
+    if frequency not in _RESAMPLE_RULE:
+        return df
+    try:
+        return df.resample(_RESAMPLE_RULE[frequency]).last()
+    except ValueError:  # pandas < 2.2 spells month-end 'M'
+        return df.resample("M" if frequency == "monthly" else "W").last()
+
+
+def _require_last_date(df, trading_date_ts):
+    if trading_date_ts != df.index[-1]:
+        logger.error(f"trading_date_ts {trading_date_ts} is not the last date in the DataFrame.")
+        raise ValueError(f"trading_date_ts {trading_date_ts} must be the last date in the DataFrame.")
+
+
+# ======================================================================================================
+# window preparation on the host (ref:31-62, 136-161): label logic, no O(n k^2) work
+def adjust_stock_prices_window(portfolio_spec, trading_date_ts, k_stock_prices_df):
+    """Last `rolling_window` (resampled) price rows ending at the trading date (ref:136-161)."""
+    k_stock_prices_df = k_stock_prices_df.sort_index()
+    _require_last_date(k_stock_prices_df, trading_date_ts)
+    window = _resample_last(k_stock_prices_df, portfolio_spec["rolling_window_frequency"])
+    return window.iloc[-portfolio_spec["rolling_window"]:]
+
+
+def calculate_excess_log_returns_from_prices(portfolio_spec, stock_prices_df, risk_free_rate_df):
+    """log(P_t/P_{t-1}) minus the risk-free rate scaled to the mean calendar gap of the window's
+    dates; rows with any NaN are dropped (ref:31-62)."""
+    log_returns = np.log(stock_prices_df / stock_prices_df.shift(1))
+    rf_rows = _rf_adjustment_for(stock_prices_df.index, risk_free_rate_df)
+    excess = log_returns - rf_rows[:, None]
+    return excess.dropna()
+
+
+def _rf_adjustment_for(index, risk_free_rate_df):
+    """Per-row risk-free adjustment for a window's date labels (ref:40-54): annual simple rate ->
+    per-period via the MEAN calendar-day gap / 365, forward-filled on labels (NaN values stay NaN)."""
+    gaps = index.to_series().diff().dt.days.dropna()
+    mean_gap = gaps.mean()
+    assert gaps.max() <= mean_gap + 4, "Unexpected large gap between return dates."
+    adjusted = (1 + risk_free_rate_df) ** (mean_gap / 365) - 1
+    adjusted.index = risk_free_rate_df.index
+    return adjusted.reindex(index, method="ffill").to_numpy().reshape(len(index), -1)[:, 0]
+
+
+def _daily_window_arrays(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df):
+    """Host packing of one window for the device: raw log-returns (n_r x k), the per-row risk-free
+    adjustment (subtracted on the device, ref:57) and the asset labels."""
+    window = adjust_stock_prices_window(portfolio_spec, trading_date_ts, k_stock_prices_df)
+    values = window.to_numpy(dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        log_returns = np.log(values[1:] / values[:-1])
+    rf_rows = _rf_adjustment_for(window.index, risk_free_rate_df)[1:]
+    keep = ~np.isnan(log_returns).any(axis=1) & ~np.isnan(rf_rows)     # dropna (ref:60)
+    return np.ascontiguousarray(log_returns[keep]), np.ascontiguousarray(rf_rows[keep]), list(window.columns)
+
+
+def _intraday_window_returns(portfolio_spec, trading_date_ts, k_stock_intraday_prices_df):
+    """Intraday log-returns of the last period (ref:299-314): bars in (date+1d-Delta, date+1d]."""
+    span = _calendar_days_of(portfolio_spec["rolling_window_frequency"])
+    lo = trading_date_ts - pd.Timedelta(days=span) + pd.Timedelta(days=1)
+    hi = trading_date_ts + pd.Timedelta(days=1)
+    idx = k_stock_intraday_prices_df.index
+    bars = k_stock_intraday_prices_df[(idx > lo) & (idx <= hi)]
+    values = bars.to_numpy(dtype=np.float64)
+    if len(values) < 2:
+        return np.empty((0, values.shape[1] if values.ndim == 2 else 0)), list(bars.columns)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        log_returns = np.log(values[1:] / values[:-1])
+    keep = ~np.isnan(log_returns).any(axis=1)
+    return np.ascontiguousarray(log_returns[keep]), list(bars.columns)
+
+
+# ======================================================================================================
+# prior hyper-parameters that are host scalars (ref:90-114, 247-282)
+def calculate_average_mcm_window(portfolio_spec, trading_date_ts, mcm_prices_df):
+    mcm_prices_df = mcm_prices_df.sort_index()
+    _require_last_date(mcm_prices_df, trading_date_ts)
+    window = _resample_last(mcm_prices_df, portfolio_spec["rolling_window_frequency"])
+    return window.iloc[-portfolio_spec["rolling_window"]:].mean().item()
+
+
+def calculate_conjugate_prior_n(portfolio_spec, trading_date_ts, mcm_prices_df):
+    """n0 = N * max(cur/avg, avg/cur) * mcm_scaling (ref:247-267, Appendix B-Q5)."""
+    average = calculate_average_mcm_window(portfolio_spec, trading_date_ts, mcm_prices_df)
+    current = mcm_prices_df.loc[trading_date_ts].item()
+    fraction = current / average if current > average else average / current
+    return portfolio_spec["rolling_window"] * fraction * portfolio_spec["mcm_scaling"]
+
+
+def calculate_conjugate_posterior_n(portfolio_spec, trading_date_ts, mcm_prices_df, conjugate_prior_n=None):
+    if conjugate_prior_n is None:
+        conjugate_prior_n = calculate_conjugate_prior_n(portfolio_spec, trading_date_ts, mcm_prices_df)
+    return conjugate_prior_n + portfolio_spec["rolling_window"]
+
+
+# ======================================================================================================
+# passive weightings: host side (prior weights / comparison portfolio), ref:661-701
+def calculate_equally_weighted_portfolio(portfolio_spec, k_stock_prices_df):
+    n = portfolio_spec["size"]
+    out = pd.DataFrame({"Weight": [1 / n] * n}, index=k_stock_prices_df.columns)
+    out.index.name = "Stock"
+    return out
+
+
+def calculate_value_weighted_portfolio(portfolio_spec, trading_date_ts, k_stock_market_caps_df):
+    caps = k_stock_market_caps_df.iloc[-1].sort_values(ascending=False)
+    assert k_stock_market_caps_df.index[-1] == trading_date_ts, "The last index date does not match the trading date."
+    out = pd.DataFrame(caps / caps.sum())
+    out.index.name = "Stock"
+    out.columns = ["Weight"]
+    return out
+
+
+def calculate_conjugate_prior_w(portfolio_spec, trading_date_ts, k_stock_prices_df, k_stock_market_caps_df,
+                                mcm_prices_df):
+    strategy = portfolio_spec["weighting_strategy"]
+    if "vw" in strategy:
+        return calculate_value_weighted_portfolio(portfolio_spec, trading_date_ts, k_stock_market_caps_df)
+    if "ew" in strategy:
+        return calculate_equally_weighted_portfolio(portfolio_spec, k_stock_prices_df)
+    logger.error("Unknown conjugate portfolio prior weights.")
+    raise ValueError("Unknown conjugate portfolio prior weights.")
+
+
+def calculate_portfolio_variance(portfolio_weights_df, covariance_matrix_df):
+    """w'Sw with label alignment (ref:64-88).  API-compatibility helper: the fused kernel forms q0
+    and q1 itself and never calls this."""
+    w = portfolio_weights_df.sort_index()
+    S = covariance_matrix_df.loc[w.index, w.index].to_numpy()
+    v = w["Weight"].to_numpy()
+    return float(v @ (S @ v))
+
+
+# ======================================================================================================
+# one window on the device
+class _WindowOnDevice:
+    """One window packed from the reference-style frames and resident on the GPU: the estimator
+    helpers below pull whichever quantity they are named after out of it."""
+
+    def __init__(self, portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df,
+                 k_stock_market_caps_df=None, k_stock_intraday_prices_df=None, mcm_prices_df=None,
+                 conjugate_prior_n=None, conjugate_prior_w_df=None, strategy=None):
+        self.spec = portfolio_spec
+        X, rf_rows, labels = _daily_window_arrays(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df)
+        self.labels = labels
+        k = len(labels)
+        self.k = k
+        N = portfolio_spec["rolling_window"]
+        conj = (strategy or portfolio_spec["weighting_strategy"]) != "jeffreys"
+        gamma = portfolio_spec.get("risk_aversion") or 1.0
+        kw = dict(panel=X, start=np.zeros(1, np.int64), rf_adj=rf_rows[None, :])
+        m = 0
+        self.n0 = None
+        self.w0_df = None
+        if conj:
+            Y, hf_labels = _intraday_window_returns(portfolio_spec, trading_date_ts, k_stock_intraday_prices_df)
+            Y = Y[:, [hf_labels.index(s) for s in labels]] if hf_labels != labels else Y
+            m = Y.shape[0]
+            if conjugate_prior_n is None:
+                conjugate_prior_n = calculate_conjugate_prior_n(portfolio_spec, trading_date_ts, mcm_prices_df)
+            if conjugate_prior_w_df is None:
+                conjugate_prior_w_df = calculate_conjugate_prior_w(portfolio_spec, trading_date_ts, k_stock_prices_df,
+                                                                   k_stock_market_caps_df, mcm_prices_df)
+            self.n0 = float(conjugate_prior_n)
+            self.w0_df = conjugate_prior_w_df
+            w0 = conjugate_prior_w_df["Weight"].reindex(labels).to_numpy(dtype=np.float64)
+            kw.update(hf_panel=Y, hf_start=np.zeros(1, np.int64), w0=w0[None, :], n0=np.array([self.n0]))
+        if portfolio_spec["size"] != k:
+            raise ValueError(f"portfolio_spec['size']={portfolio_spec['size']} but the frame has {k} assets")
+        dev = _native.default_device()
+        self.batch = _native.Batch(dev, "conjugate" if conj else "jeffreys", k, N, max(X.shape[0], 1), gamma, 1, m)
+        self.batch.upload(**kw)
+
+    def weights(self):
+        w, status, aux = self.batch.run().download()
+        _raise_on_status(status)
+        return w[0], aux[0]
+
+    def matrix(self, what):
+        M, rhs = self.batch.download_matrix(0, what)
+        return M, rhs
+
+    def frame(self, M):
+        return pd.DataFrame(M, index=self.labels, columns=self.labels)
+
+    def close(self):
+        self.batch.close()
+
+
+def _raise_on_status(status):
+    status = np.asarray(status)
+    if (status == _native.STATUS_NONFINITE).any() or (status == _native.STATUS_NOT_PD).any():
+        # ref:492-494 raises on NaN weights; a non-positive-definite S1 is reported the same way
+        # instead of returning the finite garbage an LU inverse would give (Appendix B-Q8)
+        logger.error("conjugate_posterior_w_df contains NaN values.")
+        raise ValueError("conjugate_posterior_w_df contains NaN values.")
+
+
+def _weights_frame(values, labels):
+    out = pd.DataFrame({"Weight": np.asarray(values, dtype=np.float64)}, index=pd.Index(labels))
+    return out
+
+
+def calculate_canonical_statistics_T(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df):
+    """T = X'X (ref:163-204) - fp64 MFMA Gram on the device."""
+    win = _WindowOnDevice(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df, strategy="jeffreys")
+    try:
+        T, _ = win.matrix("gram")
+        return win.frame(T)
+    finally:
+        win.close()
+
+
+def calculate_canonical_statistics_t(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df):
+    """t = X'1 (ref:206-245), returned as a one-column frame like `Series.to_frame()`."""
+    win = _WindowOnDevice(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df, strategy="jeffreys")
+    try:
+        _, t = win.matrix("gram")
+        return pd.DataFrame({0: t}, index=pd.Index(win.labels))
+    finally:
+        win.close()
+
+
+def calculate_conjugate_prior_S(portfolio_spec, trading_date_ts, k_stock_intraday_prices_df, mcm_prices_df,
+                                conjugate_prior_n=None):
+    """S0 = n0 * cov(Y) * len(Y) (ref:285-333)."""
+    if conjugate_prior_n is None:
+        conjugate_prior_n = calculate_conjugate_prior_n(portfolio_spec, trading_date_ts, mcm_prices_df)
+    Y, labels = _intraday_window_returns(portfolio_spec, trading_date_ts, k_stock_intraday_prices_df)
+    k = len(labels)
+    dev = _native.default_device()
+    # a one-row dummy daily window: only the prior phase of the kernel is read back
+    b = _native.Batch(dev, "conjugate", k, portfolio_spec["rolling_window"], 1, 1.0, 1, Y.shape[0])
+    try:
+        b.upload(panel=np.zeros((1, k)), start=np.zeros(1, np.int64), hf_panel=Y, hf_start=np.zeros(1, np.int64),
+                 w0=np.full((1, k), 1.0 / k), n0=np.array([float(conjugate_prior_n)]))
+        S0, _ = b.download_matrix(0, "prior")
+    finally:
+        b.close()
+    return pd.DataFrame(S0, index=labels, columns=labels)
+
+
+def calculate_conjugate_posterior_S(portfolio_spec, trading_date_ts, k_stock_prices_df, k_stock_intraday_prices_df,
+                                    mcm_prices_df, risk_free_rate_df, conjugate_prior_S_df=None):
+    """S1 = S0 + T (ref:335-358)."""
+    if conjugate_prior_S_df is not None:
+        T = calculate_canonical_statistics_T(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df)
+        return conjugate_prior_S_df + T
+    spec = dict(portfolio_spec)
+    win = _WindowOnDevice(spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df,
+                          k_stock_intraday_prices_df=k_stock_intraday_prices_df, mcm_prices_df=mcm_prices_df,
+                          conjugate_prior_w_df=calculate_equally_weighted_portfolio(spec, k_stock_prices_df),
+                          strategy="conjugate")
+    try:
+        S1, _ = win.matrix("posterior")
+        return win.frame(S1)
+    finally:
+        win.close()
+
+
+def _conjugate_window(portfolio_spec, trading_date_ts, k_stock_prices_df, k_stock_market_caps_df,
+                      k_stock_intraday_prices_df, mcm_prices_df, risk_free_rate_df, conjugate_prior_n=None,
+                      conjugate_prior_w_df=None):
+    return _WindowOnDevice(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df,
+                           k_stock_market_caps_df=k_stock_market_caps_df,
+                           k_stock_intraday_prices_df=k_stock_intraday_prices_df, mcm_prices_df=mcm_prices_df,
+                           conjugate_prior_n=conjugate_prior_n, conjugate_prior_w_df=conjugate_prior_w_df,
+                           strategy="conjugate")
+
+
+def calculate_conjugate_c(portfolio_spec, trading_date_ts, k_stock_prices_df, k_stock_market_caps_df,
+                          k_stock_intraday_prices_df, mcm_prices_df, conjugate_prior_n=None,
+                          conjugate_prior_S_df=None, conjugate_prior_w_df=None):
+    """c = 2 n0 / (a + sqrt(a^2 + 4 n0 w0'S0 w0)), a = n0 + size + 2 (ref:382-430)."""
+    if conjugate_prior_n is None:
+        conjugate_prior_n = calculate_conjugate_prior_n(portfolio_spec, trading_date_ts, mcm_prices_df)
+    if conjugate_prior_w_df is None:
+        conjugate_prior_w_df = calculate_conjugate_prior_w(portfolio_spec, trading_date_ts, k_stock_prices_df,
+                                                           k_stock_market_caps_df, mcm_prices_df)
+    if conjugate_prior_S_df is not None:
+        q0 = calculate_portfolio_variance(conjugate_prior_w_df, conjugate_prior_S_df)
+        a = conjugate_prior_n + portfolio_spec["size"] + 2
+        return (2 * conjugate_prior_n) / (a + (a ** 2 + 4 * conjugate_prior_n * q0) ** (1 / 2))
+    Y, labels = _intraday_window_returns(portfolio_spec, trading_date_ts, k_stock_intraday_prices_df)
+    k = len(labels)
+    dev = _native.default_device()
+    b = _native.Batch(dev, "conjugate", portfolio_spec["size"], portfolio_spec["rolling_window"], 1, 1.0, 1, Y.shape[0])
+    try:
+        w0 = conjugate_prior_w_df["Weight"].reindex(labels).to_numpy(dtype=np.float64)
+        b.upload(panel=np.zeros((1, k)), start=np.zeros(1, np.int64), hf_panel=Y, hf_start=np.zeros(1, np.int64),
+                 w0=w0[None, :], n0=np.array([float(conjugate_prior_n)]))
+        _, _, aux = b.run().download()
+    finally:
+        b.close()
+    c = float(aux[0, 2])
+    if CHECK:  # ref:420-428: the two algebraic forms of c agree
+        q0 = float(aux[0, 3])
+        a = conjugate_prior_n + portfolio_spec["size"] + 2
+        c_check = (-a + (a ** 2 + 4 * conjugate_prior_n * q0) ** (1 / 2)) / (2 * q0)
+        if not np.isclose(c, c_check, atol=1e-3):
+            raise ValueError("Portfolio c is not consistent.")
+    return c
+
+
+def calculate_conjugate_posterior_w(portfolio_spec, trading_date_ts, k_stock_prices_df, k_stock_market_caps_df,
+                                    k_stock_intraday_prices_df, mcm_prices_df, risk_free_rate_df, conjugate_c=None,
+                                    conjugate_prior_w_df=None, conjugate_prior_S_df=None,
+                                    conjugate_posterior_S_df=None):
+    """w1 = S1^-1 (c S0 w0 + t) (ref:432-496) - Cholesky solve on the device, no explicit inverse."""
+    win = _conjugate_window(portfolio_spec, trading_date_ts, k_stock_prices_df, k_stock_market_caps_df,
+                            k_stock_intraday_prices_df, mcm_prices_df, risk_free_rate_df,
+                            conjugate_prior_w_df=conjugate_prior_w_df)
+    try:
+        weights, aux = win.weights()
+        n1, q1 = aux[1], aux[4]
+        gamma = portfolio_spec.get("risk_aversion") or 1.0
+        w1 = weights * gamma * (n1 - q1) / (n1 + portfolio_spec["size"] + 2)     # undo ref:572-575, 836
+        return _weights_frame(w1, win.labels)
+    finally:
+        win.close()
+
+
+def calculate_mean_conjugate_posterior_nu(portfolio_spec, trading_date_ts, k_stock_prices_df, k_stock_market_caps_df,
+                                          k_stock_intraday_prices_df, mcm_prices_df, risk_free_rate_df,
+                                          conjugate_c=None, conjugate_prior_n=None, conjugate_posterior_n=None,
+                                          conjugate_prior_S_df=None, conjugate_posterior_S_df=None,
+                                          conjugate_prior_w_df=None, conjugate_posterior_w_df=None):
+    """nu = (n1 + size + 2) w1 / (n1 - w1'S1 w1) (ref:499-577): the posterior MEAN of the weights."""
+    win = _conjugate_window(portfolio_spec, trading_date_ts, k_stock_prices_df, k_stock_market_caps_df,
+                            k_stock_intraday_prices_df, mcm_prices_df, risk_free_rate_df,
+                            conjugate_prior_n=conjugate_prior_n, conjugate_prior_w_df=conjugate_prior_w_df)
+    try:
+        weights, _ = win.weights()
+        gamma = portfolio_spec.get("risk_aversion") or 1.0
+        return _weights_frame(weights * gamma, win.labels)
+    finally:
+        win.close()
+
+
+def calculate_mean_jeffreys_posterior_nu(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df):
+    """nu = (T - t t'/N)^-1 t (ref:580-608)."""
+    win = _WindowOnDevice(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df, strategy="jeffreys")
+    try:
+        weights, _ = win.weights()
+        gamma = portfolio_spec.get("risk_aversion") or 1.0
+        return _weights_frame(weights * gamma, win.labels)
+    finally:
+        win.close()
+
+
+def calculate_conjugate_hf_mcm_portfolio(portfolio_spec, trading_date_ts, k_stock_market_caps_df, k_stock_prices_df,
+                                         k_stock_intraday_prices_df, mcm_prices_df, risk_free_rate_df):
+    """weights = nu / risk_aversion (ref:819-836)."""
+    win = _conjugate_window(portfolio_spec, trading_date_ts, k_stock_prices_df, k_stock_market_caps_df,
+                            k_stock_intraday_prices_df, mcm_prices_df, risk_free_rate_df)
+    try:
+        weights, _ = win.weights()
+        return _weights_frame(weights, win.labels)
+    finally:
+        win.close()
+
+
+def calculate_jeffreys_portfolio(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df):
+    """weights = nu / risk_aversion (ref:838-849)."""
+    win = _WindowOnDevice(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df, strategy="jeffreys")
+    try:
+        weights, _ = win.weights()
+        return _weights_frame(weights, win.labels)
+    finally:
+        win.close()
+
+
+def _not_in_scope(name):
+    def f(*args, **kwargs):
+        raise NotImplementedError(
+            f"{name} is outside the scope of this build (SURVEY.md section 2: C9-C12); only the conjugate and "
+            "Jeffreys posteriors and the passive weightings are provided.")
+    f.__name__ = name
+    return f
+
+
+calculate_shrinkage_portfolio = _not_in_scope("calculate_shrinkage_portfolio")
+calculate_black_litterman_portfolio = _not_in_scope("calculate_black_litterman_portfolio")
+calculate_jorion_portfolio = _not_in_scope("calculate_jorion_portfolio")
+calculate_greyserman_portfolio = _not_in_scope("calculate_greyserman_portfolio")
+
+
+# ======================================================================================================
+# universe selection and dispatch (ref:611-658, 941-1052): host, reproduced not accelerated
+def _index_constituents(trading_date_ts, market_data, stock_prices_df):
+    """S&P-500 membership at the date.  The reference asks its data layer (ref:619 ->
+    data_handling.extract_unique_tickers); here `market_data["index_constituents"]` may be a callable
+    `f(date) -> list`, else the reference's `data_handling` module is used when importable, else every
+    column counts as a member (synthetic panels)."""
+    provider = market_data.get("index_constituents") if isinstance(market_data, dict) else None
+    if callable(provider):
+        return list(provider(trading_date_ts))
+    try:
+        import data_handling  # the reference's data layer, if the caller has it on sys.path
+        return list(data_handling.extract_unique_tickers(trading_date_ts, trading_date_ts))
+    except Exception:
+        return list(stock_prices_df.columns)
+
+
+def get_k_largest_stocks_market_caps(stock_market_caps_df, stock_prices_df, stock_intraday_prices_df,
+                                     trading_date_ts, portfolio_size, rolling_window_days, rolling_window_frequency,
+                                     tickers_list=None):
+    """The `portfolio_size` largest caps among stocks with a complete price window and intraday data
+    (ref:611-658).  Column-vectorised; same eligibility rules and the same nlargest ordering."""
+    if tickers_list is None:
+        tickers_list = _index_constituents(trading_date_ts, {}, stock_prices_df)
+    span = _calendar_days_of(rolling_window_frequency)
+    members = set(tickers_list)
+    cols = [c for c in stock_prices_df.columns
+            if c in members and c in stock_market_caps_df.columns and c in stock_intraday_prices_df.columns]
+    present = [t for t in tickers_list if t in stock_market_caps_df.columns]
+    logger.info(f"Fraction of tickers missing from stock_market_caps_df: "
+                f"{(len(tickers_list) - len(present)) / max(len(tickers_list), 1):.2%}")
+    recent = stock_prices_df.loc[:trading_date_ts, cols].tail(rolling_window_days)
+    full_window = recent.notna().all(axis=0)
+    bars = stock_intraday_prices_df.loc[(trading_date_ts - timedelta(days=span)):(trading_date_ts + timedelta(days=1)), cols]
+    has_bars = bars.notna().any(axis=0)
+    eligible = [c for c in cols if full_window[c] and has_bars[c]]
+    if trading_date_ts not in stock_market_caps_df.index:
+        logger.error(f"The trading date {trading_date_ts} does not exist in the market capitalizations data.")
+        raise ValueError(f"The trading date {trading_date_ts} does not exist in the market capitalizations data.")
+    return stock_market_caps_df.loc[trading_date_ts, eligible].dropna().nlargest(portfolio_size)
+
+
+class _Universe:
+    """Everything `calculate_portfolio_weights` slices out of `market_data` for one date (ref:953-988)."""
+
+    def __init__(self, trading_date_ts, portfolio_spec, market_data):
+        prices = market_data["stock_prices_df"]
+        caps = market_data["stock_market_caps_df"]
+        intraday = market_data["stock_intraday_prices_df"]
+        tickers = _index_constituents(trading_date_ts, market_data, prices)
+        # ref:960 passes the REBALANCING frequency where the callee expects the window frequency (Q7)
+        top = get_k_largest_stocks_market_caps(caps, prices, intraday, trading_date_ts, portfolio_spec["size"],
+                                               get_window_trading_days(portfolio_spec),
+                                               portfolio_spec["rebalancing_frequency"], tickers_list=tickers)
+        self.top = top
+        self.caps = caps[top.index.intersection(caps.columns)].loc[:trading_date_ts]
+        self.prices = prices[top.index.intersection(prices.columns)].loc[:trading_date_ts]
+        end_of_day = pd.Timestamp(trading_date_ts).replace(hour=23, minute=59, second=59)
+        hf = intraday[top.index.intersection(intraday.columns)]
+        self.intraday = hf.loc[hf.index <= end_of_day]
+        if self.prices.tail(get_window_trading_days(portfolio_spec)).isna().any().any():
+            logger.error("Found NA values in the filtered stock prices.")
+            raise ValueError("The filtered stock prices contain NA values.")
+
+
+def _mcm_frame(portfolio_spec, trading_date_ts, market_data):
+    key = "vix_prices_df" if "_vix_" in portfolio_spec["weighting_strategy"] else "epu_prices_df"
+    frame = market_data[key]
+    return frame.loc[frame.index <= trading_date_ts]
+
+
+def _pack_window(trading_date_ts, portfolio_spec, market_data):
+    """Host packing of one rebalancing date for the batched device call."""
+    uni = _Universe(trading_date_ts, portfolio_spec, market_data)
+    strategy = portfolio_spec["weighting_strategy"]
+    rf = market_data["risk_free_rate_df"]
+    X, rf_rows, labels = _daily_window_arrays(portfolio_spec, trading_date_ts, uni.prices, rf)
+    item = dict(labels=labels, X=X, rf=rf_rows)
+    if strategy in _CONJUGATE:
+        mcm = _mcm_frame(portfolio_spec, trading_date_ts, market_data)
+        Y, hf_labels = _intraday_window_returns(portfolio_spec, trading_date_ts, uni.intraday)
+        if hf_labels != labels:
+            Y = Y[:, [hf_labels.index(s) for s in labels]]
+        w0_df = calculate_conjugate_prior_w(portfolio_spec, trading_date_ts, uni.prices, uni.caps, mcm)
+        item.update(Y=Y, n0=float(calculate_conjugate_prior_n(portfolio_spec, trading_date_ts, mcm)),
+                    w0=w0_df["Weight"].reindex(labels).to_numpy(dtype=np.float64))
+    return item
+
+
+def _solve_packed(portfolio_spec, items):
+    """ONE device call for all packed windows of a spec: dense window-major panels + offsets."""
+    strategy = portfolio_spec["weighting_strategy"]
+    conj = strategy in _CONJUGATE
+    k = portfolio_spec["size"]
+    W = len(items)
+    for it in items:
+        if len(it["labels"]) != k:
+            raise ValueError(f"universe has {len(it['labels'])} assets, portfolio_spec['size'] is {k}")
+    n_rows = np.array([it["X"].shape[0] for it in items], dtype=np.int32)
+    n_r = int(n_rows.max())
+    start = np.concatenate([[0], np.cumsum(n_rows[:-1], dtype=np.int64)]).astype(np.int64)
+    panel = np.concatenate([it["X"] for it in items], axis=0)
+    rf_adj = np.zeros((W, n_r))
+    for i, it in enumerate(items):
+        rf_adj[i, : n_rows[i]] = it["rf"]
+    kw = dict(panel=panel, start=start, n_r=n_r, n_rows=n_rows, rf_adj=rf_adj)
+    m = 0
+    if conj:
+        counts = np.array([it["Y"].shape[0] for it in items], dtype=np.int32)
+        m = int(counts.max())
+        kw.update(hf_panel=np.concatenate([it["Y"] for it in items], axis=0),
+                  hf_start=np.concatenate([[0], np.cumsum(counts[:-1], dtype=np.int64)]).astype(np.int64),
+                  hf_count=counts, m=m, w0=np.stack([it["w0"] for it in items]),
+                  n0=np.array([it["n0"] for it in items]))
+    weights, status, aux = _native.posterior_batch("conjugate" if conj else "jeffreys", k,
+                                                   portfolio_spec["rolling_window"], portfolio_spec["risk_aversion"],
+                                                   **kw)
+    _raise_on_status(status)
+    out = []
+    for i, it in enumerate(items):
+        df = pd.DataFrame({"Weight": weights[i]}, index=pd.Index(it["labels"], name="Stock"))
+        out.append(df)
+    return out
+
+
+def calculate_portfolio_weights_batch(trading_dates, portfolio_spec, market_data):
+    """Weights for MANY rebalancing dates with one device call (the batch-native form of ref:941)."""
+    strategy = portfolio_spec["weighting_strategy"]
+    if strategy in ("vw", "ew"):
+        return [calculate_portfolio_weights(d, portfolio_spec, market_data) for d in trading_dates]
+    if strategy in _OUT_OF_SCOPE:
+        _not_in_scope(f"calculate_{strategy}_portfolio")()
+    if strategy not in _CONJUGATE and strategy != "jeffreys":
+        logger.error("Unknown weights spec.")
+        raise ValueError("Unknown weights spec.")
+    if not trading_dates:
+        return []
+    items = [_pack_window(d, portfolio_spec, market_data) for d in trading_dates]
+    return _solve_packed(portfolio_spec, items)
+
+
+def calculate_portfolio_weights(trading_date_ts, portfolio_spec, market_data):
+    """Strategy dispatch for one date (ref:941-1052); rows ordered by market cap, index 'Stock'."""
+    strategy = portfolio_spec["weighting_strategy"]
+    if strategy == "vw":
+        uni = _Universe(trading_date_ts, portfolio_spec, market_data)
+        return calculate_value_weighted_portfolio(portfolio_spec, trading_date_ts, uni.caps)
+    if strategy == "ew":
+        uni = _Universe(trading_date_ts, portfolio_spec, market_data)
+        return calculate_equally_weighted_portfolio(portfolio_spec, uni.prices)
+    return calculate_portfolio_weights_batch([trading_date_ts], portfolio_spec, market_data)[0]
+
+
+# ======================================================================================================
+# backtest engine (ref:1054-1238)
+def compute_portfolio_turnover(portfolio_weights_before_df, portfolio_weights_after_df):
+    """Half the L1 change of the weights, the risk-free position included (ref:1054-1075)."""
+    both = portfolio_weights_before_df.merge(portfolio_weights_after_df, how="outer", left_index=True,
+                                             right_index=True, suffixes=("_before", "_after")).fillna(0)
+    traded = (both["Weight_before"] - both["Weight_after"]).abs().sum()
+    cash = abs(portfolio_weights_before_df["Weight"].sum() - portfolio_weights_after_df["Weight"].sum())
+    return (traded + cash) / 2
+
+
+def calculate_average_distance_to_comparison_portfolio(portfolio_weights_df, portfolio_spec, trading_date_ts,
+                                                       market_data, comparison_portfolio_weighting_strategy):
+    """Mean absolute distance to the value-weighted portfolio of the same universe (ref:1077-1104)."""
+    if comparison_portfolio_weighting_strategy != "vw":
+        raise ValueError("Unknown comparison portfolio.")
+    comparison_spec = {"size": portfolio_spec["size"], "rebalancing_frequency": portfolio_spec["rebalancing_frequency"],
+                       "rolling_window": portfolio_spec["rolling_window"],
+                       "rolling_window_frequency": portfolio_spec["rolling_window_frequency"],
+                       "weighting_strategy": "vw"}
+    comparison = calculate_portfolio_weights(trading_date_ts, comparison_spec, market_data)
+    if not portfolio_weights_df.index.equals(comparison.index):
+        raise ValueError("The portfolios do not match exactly in terms of stocks.")
+    scaling = portfolio_spec["risk_aversion"] if portfolio_spec.get("risk_aversion") is not None else 1
+    return np.abs(portfolio_weights_df * scaling - comparison).mean().item()
+
+
+def rebalancing_schedule(trading_dates, rebalancing_frequency):
+    """Rebalancing dates of a backtest (ref:1166-1176): they depend on the date list only, which is
+    what lets `backtest_portfolio` solve all windows in one batch before replaying the P&L."""
+    out, last = [], None
+    for ts in trading_dates:
+        if last is None or rebalancing_frequency == "daily":
+            hit = True
+        elif rebalancing_frequency == "weekly":
+            hit = ts.weekday() == 2 or (ts - last).days > 7
+        elif rebalancing_frequency == "monthly":
+            hit = ts.month != last.month
+        else:
+            logger.error("Unknown rebalancing frequency.")
+            raise ValueError("Unknown rebalancing frequency.")
+        if hit:
+            out.append(ts)
+            last = ts
+    return out
+
+
+class Portfolio:
+    """Daily P&L, weight drift, rebalancing, turnover and weight metrics (ref:1106-1219)."""
+
+    def __init__(self, ts_start_date, portfolio_spec, precomputed_weights=None):
+        self.ts_start_date = ts_start_date
+        self.portfolio_spec = portfolio_spec
+        self.portfolio_simple_returns_series = pd.Series(dtype="float64", name=portfolio_spec["display_name"])
+        self.portfolio_turnover_series = pd.Series(dtype="float64", name=portfolio_spec["display_name"])
+        self.portfolio_weights_metrics_df = pd.DataFrame(dtype="float64")
+        self.last_rebalance_date_ts = None
+        self._precomputed = precomputed_weights or {}
+
+    def get_portfolio_simple_returns(self):
+        return self.portfolio_simple_returns_series
+
+    def get_portfolio_turnover(self):
+        return self.portfolio_turnover_series
+
+    def get_portfolio_weights_metrics(self):
+        return self.portfolio_weights_metrics_df
+
+    def _mark_to_market(self, trading_date_ts, market_data):
+        w = self.portfolio_weights_df["Weight"]
+        returns = market_data["stock_simple_returns_df"].loc[trading_date_ts].reindex(self.portfolio_weights_df.index)
+        rf_annual = market_data["risk_free_rate_df"].asof(trading_date_ts).iloc[0]
+        rf_daily = (rf_annual + 1) ** (1 / 252) - 1
+        cash = 1 - w.sum()
+        self.portfolio_simple_returns_series[trading_date_ts] = (returns * w).sum() + cash * rf_daily   # ref:1137-1145
+        cash_after = cash * (1 + rf_daily)
+        drifted = w * (1 + returns)
+        total = drifted.sum() + cash_after
+        self.portfolio_weights_df["Weight"] = drifted / total                                          # ref:1152-1159
+        if abs((self.portfolio_weights_df["Weight"].values.sum() + cash_after / total) - 1) > 1e-5:
+            logger.error("Weights do not sum to 1.")
+            raise ValueError("Weights do not sum to 1.")
+
+    def _is_rebalance_day(self, trading_date_ts):
+        freq = self.portfolio_spec["rebalancing_frequency"]
+        if self.last_rebalance_date_ts is None or freq == "daily":
+            return True
+        if freq == "weekly":
+            return trading_date_ts.weekday() == 2 or (trading_date_ts - self.last_rebalance_date_ts).days > 7
+        if freq == "monthly":
+            return trading_date_ts.month != self.last_rebalance_date_ts.month
+        logger.error("Unknown rebalancing frequency.")
+        raise ValueError("Unknown rebalancing frequency.")
+
+    def update_portfolio(self, trading_date_ts, market_data):
+        if self.ts_start_date != trading_date_ts:
+            self._mark_to_market(trading_date_ts, market_data)
+        if not self._is_rebalance_day(trading_date_ts):
+            return
+        first = self.last_rebalance_date_ts is None
+        before = None if first else self.portfolio_weights_df.copy()
+        if trading_date_ts in self._precomputed:
+            self.portfolio_weights_df = self._precomputed[trading_date_ts].copy()
+        else:
+            self.portfolio_weights_df = calculate_portfolio_weights(trading_date_ts, self.portfolio_spec, market_data)
+        distance = calculate_average_distance_to_comparison_portfolio(self.portfolio_weights_df, self.portfolio_spec,
+                                                                      trading_date_ts, market_data, "vw")
+        w = self.portfolio_weights_df["Weight"]
+        row = pd.DataFrame({"max_long": [w[w > 0].max()], "max_short": [w[w < 0].min()],
+                            "avg_long": [w[w > 0].mean()], "avg_short": [w[w < 0].mean()],
+                            "average_distance_to_comparison_portfolio": [distance]}, index=[trading_date_ts])
+        self.portfolio_weights_metrics_df = pd.concat([self.portfolio_weights_metrics_df, row])
+        if not first:
+            turnover = compute_portfolio_turnover(before, self.portfolio_weights_df)
+            self.portfolio_turnover_series[trading_date_ts] = turnover
+            self.portfolio_simple_returns_series[trading_date_ts] -= self.portfolio_spec["turnover_cost"] / 10000 * turnover
+        logger.info(f"Portfolio size {trading_date_ts}: {len(self.portfolio_weights_df.index)}")
+        self.last_rebalance_date_ts = trading_date_ts
+
+
+def backtest_portfolio(portfolio_spec, ts_start_date, ts_end_date, market_data):
+    """Same inputs and outputs as ref:1221-1238; all posterior solves happen in one device batch."""
+    trading_dates = [pd.Timestamp(ts) for ts in market_data["stock_prices_df"].index]
+    trading_dates = [ts for ts in trading_dates if ts_start_date <= ts <= ts_end_date]
+    strategy = portfolio_spec["weighting_strategy"]
+    precomputed = {}
+    if strategy in _CONJUGATE or strategy == "jeffreys":
+        rebalance_dates = rebalancing_schedule(trading_dates, portfolio_spec["rebalancing_frequency"])
+        frames = calculate_portfolio_weights_batch(rebalance_dates, portfolio_spec, market_data)
+        precomputed = dict(zip(rebalance_dates, frames))
+    portfolio = Portfolio(trading_dates[0], portfolio_spec, precomputed_weights=precomputed)
+    for ts in trading_dates:
+        portfolio.update_portfolio(ts, market_data)
+    return {"portfolio_simple_returns_series": portfolio.get_portfolio_simple_returns(),
+            "portfolio_turnover_series": portfolio.get_portfolio_turnover(),
+            "portfolio_weights_metrics_df": portfolio.get_portfolio_weights_metrics()}

@@ -126,3 +126,38 @@ def make_market_data(n_tickers: int = 14, n_days: int = 165, seed: int = 2024000
         "sp500_simple_returns_df": sp500_simple_returns_df,
     }
     return market_data, tickers
+
+
+def window_frames(inp, w, tickers):
+    """DataFrames for window w of a `make_kernel_inputs` dict, the way the reference wants them:
+    prices P = 100*exp(cumsum(x)) (N rows), intraday prices (m+1 bars on the trading date), caps
+    (so that value weights == w0), rf = 0.  Returns (date, prices, intraday, caps, rf)."""
+    import pandas as pd
+
+    k, N, n_r, m = inp["k"], inp["N"], inp["n_r"], inp["m"]
+    s = int(inp["start"][w])
+    x = inp["panel"][s:s + n_r]
+    logp = np.concatenate([np.zeros((1, k)), np.cumsum(x, axis=0)], axis=0)
+    days = pd.bdate_range("2020-01-01", periods=N)
+    date = days[-1]
+    prices_df = pd.DataFrame(100.0 * np.exp(logp), index=days, columns=tickers)
+    hs = int(inp["hf_start"][w])
+    y = inp["hf_panel"][hs:hs + m]
+    logh = np.concatenate([np.zeros((1, k)), np.cumsum(y, axis=0)], axis=0)
+    # all m+1 bars are stamped inside the trading date, so that the reference's daily filter
+    # (date, date+1d] (ref:310-312) keeps exactly these bars whatever m is
+    step = pd.Timedelta(seconds=int(6.5 * 3600 / (m + 1)))
+    bar_idx = [date + pd.Timedelta(hours=9, minutes=30) + i * step for i in range(m + 1)]
+    intraday_df = pd.DataFrame(50.0 * np.exp(logh), index=pd.DatetimeIndex(bar_idx), columns=tickers)
+    caps_df = pd.DataFrame([inp["w0"][w] * 1e12], index=[date], columns=tickers)
+    rf_df = pd.DataFrame({"DTB3": np.zeros(N)}, index=days)
+    return date, prices_df, intraday_df, caps_df, rf_df
+
+
+def mcm_frame_for_n0(n0_target, N, index):
+    """A market-condition series whose reference statistics (ref:112, 257-265) give frac = n0_target/N:
+    N-1 ones and a last value v > 1 have avg = (N-1+v)/N and frac = v/avg."""
+    import pandas as pd
+    frac = n0_target / N
+    v = frac * (N - 1) / (N - frac)
+    return pd.DataFrame({"VIX": np.r_[np.ones(N - 1), v]}, index=index)

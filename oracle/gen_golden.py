@@ -58,28 +58,7 @@ def sha(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
 
 
-def window_frames(inp, w, tickers):
-    """DataFrames for window w of a `make_kernel_inputs` dict, the way the reference wants them:
-    prices P = 100*exp(cumsum(x)) (N rows), intraday prices (m+1 bars on the trading date), caps
-    (so that value weights == w0), a VIX series whose window statistics give n0, rf = 0."""
-    k, N, n_r, m = inp["k"], inp["N"], inp["n_r"], inp["m"]
-    s = int(inp["start"][w])
-    x = inp["panel"][s:s + n_r]
-    logp = np.concatenate([np.zeros((1, k)), np.cumsum(x, axis=0)], axis=0)
-    days = pd.bdate_range("2020-01-01", periods=N)
-    date = days[-1]
-    prices_df = pd.DataFrame(100.0 * np.exp(logp), index=days, columns=tickers)
-    hs = int(inp["hf_start"][w])
-    y = inp["hf_panel"][hs:hs + m]
-    logh = np.concatenate([np.zeros((1, k)), np.cumsum(y, axis=0)], axis=0)
-    # all m+1 bars are stamped inside the trading date, so that the reference's daily filter
-    # (date, date+1d] (ref:310-312) keeps exactly these bars whatever m is
-    step = pd.Timedelta(seconds=int(6.5 * 3600 / (m + 1)))
-    bar_idx = [date + pd.Timedelta(hours=9, minutes=30) + i * step for i in range(m + 1)]
-    intraday_df = pd.DataFrame(50.0 * np.exp(logh), index=pd.DatetimeIndex(bar_idx), columns=tickers)
-    caps_df = pd.DataFrame([inp["w0"][w] * 1e12], index=[date], columns=tickers)
-    rf_df = pd.DataFrame({"DTB3": np.zeros(N)}, index=days)
-    return date, prices_df, intraday_df, caps_df, rf_df
+window_frames = synthetic.window_frames
 
 
 def gen_single_windows(pc, name, k, N, hf_days, W, seed, strategies, store_inputs, window_freq="daily"):
@@ -107,9 +86,7 @@ def gen_single_windows(pc, name, k, N, hf_days, W, seed, strategies, store_input
             # conjugate: the MCM frame is built so that the reference's own n0 equals inp["n0"][w]
             # exactly: a window of N-1 ones and a last value v has avg = (N-1+v)/N and, for v > 1,
             # frac = v/avg -> choose v from the target frac, then store the reference's n0.
-            frac = inp["n0"][w] / N
-            v = frac * (N - 1) / (N - frac)
-            mcm_df = pd.DataFrame({"VIX": np.r_[np.ones(N - 1), v]}, index=prices_df.index)
+            mcm_df = synthetic.mcm_frame_for_n0(inp["n0"][w], N, prices_df.index)
             n0 = pc.calculate_conjugate_prior_n(spec, date, mcm_df)
             S0 = pc.calculate_conjugate_prior_S(spec, date, intraday_df, mcm_df)
             w0 = pc.calculate_conjugate_prior_w(spec, date, prices_df, caps_df, mcm_df)
