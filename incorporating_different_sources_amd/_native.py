@@ -12,7 +12,8 @@ from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_void_
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtangency.so")
+# TANGENCY_LIB selects another build of the same library (tuning experiments); default: the in-tree one
+LIB_PATH = os.environ.get("TANGENCY_LIB") or os.path.join(_HERE, "libtangency.so")
 
 TP_OK = 0
 TP_ERR_INVALID = -1
@@ -29,7 +30,7 @@ UNIQUE_ID_BYTES = 128
 # every symbol include/tangency_posterior.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTS = [
     "tp_version", "tp_max_assets", "tp_create", "tp_destroy", "tp_last_error", "tp_device_info",
-    "tp_batch_create", "tp_batch_upload", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1", "tp_batch_download_matrix",
+    "tp_batch_create", "tp_batch_upload", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1", "tp_batch_download_matrix", "tp_batch_debug_stamps",
     "tp_batch_destroy", "tp_posterior_batch", "tp_synchronize", "tp_last_timing", "tp_region_begin",
     "tp_region_end", "tp_last_launch", "tp_comm_unique_id", "tp_comm_init", "tp_comm_destroy",
     "tp_batch_gather",
@@ -75,6 +76,7 @@ def _load():
     lib.tp_batch_download.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int32), POINTER(c_double)]
     lib.tp_batch_download_S1.argtypes = [c_void_p, c_int64, POINTER(c_double)]
     lib.tp_batch_download_matrix.argtypes = [c_void_p, c_int64, c_int, POINTER(c_double), POINTER(c_double)]
+    lib.tp_batch_debug_stamps.argtypes = [c_void_p, POINTER(c_int64)]
     lib.tp_batch_destroy.argtypes = [c_void_p]
     lib.tp_posterior_batch.argtypes = [c_void_p, POINTER(tp_params_t), c_int64, POINTER(tp_inputs_t),
                                        POINTER(c_double), POINTER(c_int32), POINTER(c_double)]
@@ -273,6 +275,12 @@ class Batch:
         rhs = np.empty(self.k, dtype=np.float64)
         self.dev._check(lib.tp_batch_download_matrix(self._b, int(w), int(code), _ptr(M, c_double), _ptr(rhs, c_double)))
         return M, rhs
+
+    def debug_stamps(self) -> np.ndarray:
+        """[W x 8] shader-clock stamps at the kernel's phase boundaries (TP_STAMP builds only)."""
+        st = np.zeros((self.W, 8), dtype=np.int64)
+        self.dev._check(lib.tp_batch_debug_stamps(self._b, _ptr(st, c_int64)))
+        return st
 
     def gather(self, root=0):
         """One RCCL gather of every rank's [W x k] weights (and statuses) to `root`."""

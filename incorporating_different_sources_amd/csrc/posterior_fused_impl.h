@@ -38,6 +38,20 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// how many 4-row MFMA k-steps of a staged chunk are unrolled together (operand reads in flight)
+#ifndef TP_KSTEP_UNROLL
+#define TP_KSTEP_UNROLL 1
+#endif
+constexpr int tp_kstep_unroll = TP_KSTEP_UNROLL;
+
+// Diagnostic build only (make TP_STAMP=1): per-window s_memtime stamps at the phase boundaries, written
+// to a buffer of their own (never into an output).  The product build compiles none of this.
+#ifdef TP_STAMP
+#define TP_MARK(slot) do { if (A.stamps && (tid0 == 0)) A.stamps[(w - A.w_first) * 8 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TP_MARK(slot) do { } while (0)
+#endif
+
 namespace {
 
 template <int NT_, int NW_>
@@ -54,7 +68,6 @@ struct Cfg {
     static constexpr int ROWS_PER_PASS = NTHREADS / 16;  // 16 threads per staged row
     static constexpr int PASSES = CH / ROWS_PER_PASS;
     static constexpr int COLCAP = 48 * NW;               // non-diagonal columns the waves can eliminate at once
-    static_assert(16 * (NT - 1) + 16 <= COLCAP, "block row does not fit the elimination lanes");
     static_assert(PASSES >= 1, "bad staging geometry");
     // LDS carve (doubles)
     static constexpr int STAGE = CH * LDX;               // one staging buffer; buffer 0 doubles as the block-row
@@ -66,8 +79,8 @@ struct Cfg {
     static constexpr int OFF_W0 = OFF_YBAR + KP;         // [KP] prior weights, zero padded
     static constexpr int OFF_YVEC = OFF_W0 + KP;         // [KP] y = R^-T b
     static constexpr int OFF_WVEC = OFF_YVEC + KP;       // [KP] solution
-    static constexpr int OFF_DIAG = OFF_WVEC + KP;       // [16][16] factored diagonal tile R_jj
-    static constexpr int OFF_SCAL = OFF_DIAG + 256;      // [8] scalars
+    static constexpr int OFF_DIAG = OFF_WVEC + KP;       // 2 x [16][16] diagonal tile handed to the eliminating wave
+    static constexpr int OFF_SCAL = OFF_DIAG + 512;      // [8] scalars: 0 = z'z, 1 = not-positive-definite flag
     static constexpr int LDS_DOUBLES = OFF_SCAL + 8;
     static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
 };
@@ -78,13 +91,42 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
+// rotate right by N lanes inside each row of 16 lanes (DPP row_ror:N) - no LDS crossbar involved
+template <int N>
+__device__ __forceinline__ double dpp_row_ror(double v) {
+    // every lane of a row_ror has a source lane: no "old" value is needed (mov_dpp leaves it undefined)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x120 + N, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x120 + N, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
 // sum over the 16 lanes that share lane>>4 (one MFMA row group); every lane gets the sum
 __device__ __forceinline__ double rowgroup_sum16(double v) {
-    v += __shfl_xor(v, 8, 16);
-    v += __shfl_xor(v, 4, 16);
-    v += __shfl_xor(v, 2, 16);
-    v += __shfl_xor(v, 1, 16);
+    v += dpp_row_ror<8>(v);
+    v += dpp_row_ror<4>(v);
+    v += dpp_row_ror<2>(v);
+    v += dpp_row_ror<1>(v);
     return v;
+}
+
+// An identity the optimiser cannot see through.  Every phase re-derives its lane constants (row/column
+// of the lane, LDS addresses, masks) from a laundered thread id, so that common-subexpression
+// elimination and loop-invariant hoisting cannot stretch those values' live ranges over the whole
+// kernel - that, not the accumulators, is what drove the register count to the 256 ceiling.
+__device__ __forceinline__ int fresh(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// 1/sqrt(d): v_rsq_f64 seed (about 2^-24 relative) + two Newton steps; a non-positive or NaN d
+// gives NaN/Inf, which the caller reports as "not positive definite"
+__device__ __forceinline__ double rsqrt_nr(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    double e = fma(-(d * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-(d * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
+    return y;
 }
 
 __device__ __forceinline__ double wave_sum64(double v) {
@@ -166,19 +208,20 @@ __device__ __forceinline__ void load_chunk(const RowSource& src, const int* __re
     for (int ps = 0; ps < C::PASSES; ++ps) {
         const int r = chunk * C::CH + ps * C::ROWS_PER_PASS + (tid >> 4);
         const bool rv = r < src.count;
-        long long row = 0;
+        const int rc = rv ? r : src.count - 1;            // clamp (count >= 1 is validated on the host)
+        const long long row = src.ridx ? (long long)src.ridx[rc] : src.first + rc;
         double sub = 0.0;
-        if (rv) {
-            row = src.ridx ? (long long)src.ridx[r] : src.first + r;
-            if (!HF && src.sub_row) sub = src.sub_row[r];
-        }
+        if (!HF && src.sub_row) sub = src.sub_row[rc];
         const double* p = src.base + row * (long long)src.ld;
 #pragma unroll
         for (int i = 0; i < C::NT; ++i) {
             const int c = cb + 16 * i;
-            double x = 0.0;
-            if (rv && c < k) x = p[cols ? cols[c] : c] - sub;
-            v[ps][i] = x;
+            // k >= 16 (NT-1): only the last 16-column group can hold columns >= k.  Loads are
+            // unconditional on clamped addresses and masked by selects (no divergent branches).
+            const bool cv = (i < C::NT - 1) || (c < k);
+            const int cl = cv ? c : k - 1;
+            const double x = p[cols ? cols[cl] : cl] - sub;
+            v[ps][i] = (rv && cv) ? x : 0.0;
         }
     }
 }
@@ -189,7 +232,8 @@ template <class C, bool HF>
 __device__ __forceinline__ void store_chunk(double* __restrict__ buf, const double* __restrict__ lds, int k,
                                             int chunk, int count, int tid, double (&v)[C::PASSES][C::NT]) {
     const int cb = tid & 15;
-    const int kI = k >> 4, kc = k & 15;
+    constexpr int kI = C::NT - 1;            // the border column k always lies in the last 16-column group
+    const int kc = k - 16 * kI;
 #pragma unroll
     for (int ps = 0; ps < C::PASSES; ++ps) {
         const int rl = ps * C::ROWS_PER_PASS + (tid >> 4);
@@ -199,17 +243,14 @@ __device__ __forceinline__ void store_chunk(double* __restrict__ buf, const doub
 #pragma unroll
             for (int i = 0; i < C::NT; ++i) {
                 const int c = cb + 16 * i;
-                if (rv && c < k) v[ps][i] -= lds[C::OFF_YBAR + c];
-                z += v[ps][i] * lds[C::OFF_W0 + c];     // w0 is zero for c >= k
+                const bool cv = (i < kI) || (c < k);
+                v[ps][i] = (rv && cv) ? v[ps][i] - lds[C::OFF_YBAR + c] : 0.0;   // ybar, w0 are zero-padded
+                z = fma(v[ps][i], lds[C::OFF_W0 + c], z);
             }
             z = rowgroup_sum16(z);
-#pragma unroll
-            for (int i = 0; i < C::NT; ++i)
-                if (i == kI && cb == kc) v[ps][i] = z;  // border column: z_r = (y_r - ybar).w0
+            if (cb == kc) v[ps][kI] = z;                 // border column: z_r = (y_r - ybar).w0
         } else {
-#pragma unroll
-            for (int i = 0; i < C::NT; ++i)
-                if (i == kI && cb == kc) v[ps][i] = rv ? 1.0 : 0.0;  // border column: ones -> t = X'1
+            if (cb == kc) v[ps][kI] = rv ? 1.0 : 0.0;    // border column: ones -> t = X'1
         }
 #pragma unroll
         for (int i = 0; i < C::NT; ++i) buf[rl * C::LDX + cb + 16 * i] = v[ps][i];
@@ -221,7 +262,7 @@ __device__ __forceinline__ void store_chunk(double* __restrict__ buf, const doub
 // one ds_read_b64 at an immediate offset.
 template <class C, int WV, int NROWS, bool NEG, class Pick>
 __device__ __forceinline__ void mfma_tiles(const double* __restrict__ lanebase, d4 (&acc)[C::SLOTS], Pick pick) {
-#pragma unroll
+#pragma clang loop unroll_count(tp_kstep_unroll)
     for (int s4 = 0; s4 < NROWS / 4; ++s4) {
         for_tiles<C, WV>([&](auto sc, auto Ic, auto Jc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
@@ -237,20 +278,24 @@ __device__ __forceinline__ void mfma_tiles(const double* __restrict__ lanebase, 
 
 template <class C, bool HF, int FIX>
 __device__ __forceinline__ void gram_phase(const RowSource& src, const int* __restrict__ cols, int k, double* lds,
-                                           int tid, int wv, int fq, int fr, d4 (&acc)[C::SLOTS]) {
+                                           int tid0, int wv, d4 (&acc)[C::SLOTS]) {
     const int nchunks = (src.count + C::CH - 1) / C::CH;
     double v[C::PASSES][C::NT];
     if (nchunks > 0) {
+        const int tid = fresh(tid0);
         load_chunk<C, HF>(src, cols, k, 0, tid, v);
         store_chunk<C, HF>(lds + C::OFF_STAGE0, lds, k, 0, src.count, tid, v);
     }
     __syncthreads();
 #pragma nounroll
     for (int ch = 0; ch < nchunks; ++ch) {
+        const int tid = fresh(tid0);                  // per-chunk lane constants: nothing hoisted out of the loop
+        const int fr = tid & 15, fq = (tid & 63) >> 4;
         double* cur = lds + ((ch & 1) ? C::OFF_STAGE1 : C::OFF_STAGE0);
         double* nxt = lds + ((ch & 1) ? C::OFF_STAGE0 : C::OFF_STAGE1);
         const bool more = ch + 1 < nchunks;
         if (more) load_chunk<C, HF>(src, cols, k, ch + 1, tid, v);       // global loads in flight under the MFMAs
+        __builtin_amdgcn_sched_barrier(0);   // the scheduler must not sink these loads below the MFMA block
         const double* lanebase = cur + fq * C::LDX + fr;
         wave_sel<C::NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
             mfma_tiles<C, decltype(wc)::value, C::CH, false>(lanebase, acc, [](int, int) { return true; });
@@ -261,13 +306,19 @@ __device__ __forceinline__ void gram_phase(const RowSource& src, const int* __re
 }
 
 template <int NT, int NW, int FIX>
-__device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, const int tid, const int wv) {
+__device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, const int tid0, const int wv) {
     using C = Cfg<NT, NW>;
-    const int lane = tid & 63;
-    const int fr = lane & 15, fq = lane >> 4;
+// lane constants of one phase: tid, lane, MFMA fragment column fr and row group fq, border-column masks
+#define TP_LANE_CONSTANTS() \
+    const int tid = fresh(tid0); const int lane = tid & 63; const int fr = lane & 15; const int fq = lane >> 4; \
+    const bool colv = fr < kc; (void)lane; (void)fq; (void)colv
     const int k = A.k;
-    const int kI = k >> 4, kc = k & 15;        // tile column / local column of the border column
-    const int NTB = (k + 15) >> 4;             // block rows that hold pivots
+    // NT = ceil((k+1)/16): the border column k lies in the last tile column, always
+    __builtin_assume(k >= 16 * (NT - 1));
+    __builtin_assume(k <= 16 * NT - 1);
+    constexpr int kI = NT - 1;                 // tile column of the border column
+    const int kc = k - 16 * kI;                // its local column (0..15) = number of real rows/cols in block kI
+    const int NTB = (kc == 0) ? NT - 1 : NT;   // block rows that hold pivots
     const long long w = A.w_first + blockIdx.x;   // one workgroup per window
     if (w >= A.w_first + A.w_count) return;
 
@@ -279,12 +330,14 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
 
     double n0 = 0.0, cc = 0.0, q0 = 0.0;
     const bool conj = A.strategy == 0;
+    if (tid0 == 0) lds[C::OFF_SCAL + 1] = 0.0;   // not-positive-definite flag (barriers of the Gram phase publish it)
     // debug read-back of one window's matrix (tp_batch_download_matrix): 1 = prior scatter S0 and
     // c S0 w0, 2 = canonical statistics T and t only, 3 = posterior S1 (or Jeffreys J) and rhs
     const int dbg = (A.dbg_S1 != nullptr && w == A.dbg_w) ? A.dbg_mode : 0;
 
     // dump the current bordered matrix: [k x k] symmetric part, then the border column
     auto dump_matrix = [&]() __attribute__((always_inline)) {
+        TP_LANE_CONSTANTS();
         wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
             for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
                 constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
@@ -310,34 +363,64 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
         hs.first = A.hf_start ? A.hf_start[w] : 0;
         hs.sub_row = nullptr;
         hs.count = A.hf_count ? A.hf_count[w] : A.m;
-        // ---- phase A: column means (ref:317, DataFrame.cov centres first) and w0 into LDS
-        for (int c = tid; c < C::KP; c += C::NTHREADS) {
-            double sum = 0.0, wz = 0.0;
-            if (c < k) {
-                const int gc = cols ? cols[c] : c;
-                for (int r = 0; r < hs.count; ++r) {
-                    const long long row = hs.ridx ? (long long)hs.ridx[r] : hs.first + r;
-                    sum += hs.base[row * (long long)hs.ld + gc];
+        TP_MARK(0);
+        // ---- phase A: column means (ref:317, DataFrame.cov centres first) and w0 into LDS.
+        // Same thread geometry as the staging (16 threads per row, 16-lane coalesced segments): every
+        // thread sums its rows, the ROWS_PER_PASS partial rows meet in LDS and are added in row order.
+        {
+            TP_LANE_CONSTANTS();
+            double cs[C::NT];
+#pragma unroll
+            for (int i = 0; i < C::NT; ++i) cs[i] = 0.0;
+            const int cb = tid & 15;
+            const int iters = (hs.count + C::ROWS_PER_PASS - 1) / C::ROWS_PER_PASS;
+#pragma unroll 4
+            for (int it = 0; it < iters; ++it) {                            // loads of 4 iterations in flight
+                const int r = it * C::ROWS_PER_PASS + (tid >> 4);
+                const bool rv = r < hs.count;
+                const int rc = rv ? r : hs.count - 1;
+                const long long row = hs.ridx ? (long long)hs.ridx[rc] : hs.first + rc;
+                const double* p = hs.base + row * (long long)hs.ld;
+#pragma unroll
+                for (int i = 0; i < C::NT; ++i) {
+                    const int c = cb + 16 * i;
+                    const bool cv = (i < C::NT - 1) || (c < k);
+                    const int cl = cv ? c : k - 1;                          // clamp: load unconditionally
+                    const double x = p[cols ? cols[cl] : cl];
+                    cs[i] += (rv && cv) ? x : 0.0;
                 }
-                sum /= (double)hs.count;
-                wz = A.w0[w * k + c];
             }
-            lds[C::OFF_YBAR + c] = sum;
-            lds[C::OFF_W0 + c] = wz;
+            double* part = lds + C::OFF_STAGE0;                             // [ROWS_PER_PASS][LDX]
+#pragma unroll
+            for (int i = 0; i < C::NT; ++i) part[(tid >> 4) * C::LDX + cb + 16 * i] = cs[i];
+            __syncthreads();
+            for (int c = tid; c < C::KP; c += C::NTHREADS) {
+                double sum = 0.0;
+#pragma unroll 4
+                for (int r = 0; r < C::ROWS_PER_PASS; ++r) sum += part[r * C::LDX + c];
+                lds[C::OFF_YBAR + c] = (c < k) ? sum / (double)hs.count : 0.0;
+                lds[C::OFF_W0 + c] = (c < k) ? A.w0[w * k + c] : 0.0;
+            }
+            __syncthreads();
         }
-        __syncthreads();
+        TP_MARK(1);
         // ---- phase B: centred intraday Gram
-        gram_phase<C, true, FIX>(hs, cols, k, lds, tid, wv, fq, fr, acc);
+        gram_phase<C, true, FIX>(hs, cols, k, lds, tid0, wv, acc);
+        TP_MARK(2);
         // ---- phase C: q0, c, scaling (ref:333, 415-418)
+        {
+        TP_LANE_CONSTANTS();
         const double mm = (double)hs.count;
         const double sc = n0 * (mm / (mm - 1.0));
         wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
             for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
                 constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
-                if (I == J && I == kI && fr == kc && fq == (kc & 3)) {
+                if constexpr (I == kI && J == kI) {
+                    if (fr == kc && fq == (kc & 3)) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (r == (kc >> 2)) lds[C::OFF_SCAL + 0] = acc[s][r];   // z'z = w0'C w0
+                        for (int r = 0; r < 4; ++r)
+                            if (r == (kc >> 2)) lds[C::OFF_SCAL + 0] = acc[s][r];   // z'z = w0'C w0
+                    }
                 }
             });
         });
@@ -345,22 +428,26 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
         q0 = sc * lds[C::OFF_SCAL + 0];
         const double a = n0 + k + 2;
         cc = (2 * n0) / (a + sqrt(a * a + 4 * n0 * q0));
+        // S0 = sc * C on the real columns, c * sc * C w0 in the border column, zero beyond
+        const double fcol = colv ? sc : ((fr == kc) ? cc * sc : 0.0);
         wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
             for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
                 constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
-                const int gj = 16 * J + fr;
+                if constexpr (J < kI) {
+                    acc[s] *= sc;
+                } else if constexpr (I < kI) {
+                    acc[s] *= fcol;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gi = 16 * I + fq + 4 * r;
-                    double f = 0.0;
-                    if (gi < k) f = (gj < k) ? sc : ((gj == k) ? cc * sc : 0.0);
-                    acc[s][r] *= f;
+                    for (int r = 0; r < 4; ++r) acc[s][r] *= (fq + 4 * r < kc) ? fcol : 0.0;
                 }
             });
         });
+        }
         if (dbg == 1) { dump_matrix(); return; }
     }
 
+    TP_MARK(3);
     // ---- phase D: daily Gram (ref:180) + t in the border column (ref:222)
     {
         RowSource ds;
@@ -369,19 +456,22 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
         ds.first = A.start ? A.start[w] : 0;
         ds.sub_row = A.rf_adj ? A.rf_adj + w * (long long)A.n_r : nullptr;
         ds.count = A.n_rows ? A.n_rows[w] : A.n_r;
-        gram_phase<C, false, FIX>(ds, cols, k, lds, tid, wv, fq, fr, acc);
+        gram_phase<C, false, FIX>(ds, cols, k, lds, tid0, wv, acc);
     }
 
+    {
+    TP_LANE_CONSTANTS();
     // rows >= k of the bordered matrix are never pivots: clear them (they hold 1'X, n_r, ...);
     // Jeffreys: publish t (border column) for the rank-one correction
     wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
         for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
+            if constexpr (J == kI) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gi = 16 * I + fq + 4 * r;
-                if (gi >= k) acc[s][r] = 0.0;
-                if (!conj && J == kI && fr == kc) lds[C::OFF_YBAR + gi] = acc[s][r];
+                for (int r = 0; r < 4; ++r) {
+                    if (I == kI && fq + 4 * r >= kc) acc[s][r] = 0.0;
+                    if (!conj && fr == kc) lds[C::OFF_YBAR + 16 * I + fq + 4 * r] = acc[s][r];
+                }
             }
         });
     });
@@ -394,129 +484,146 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
         wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
             for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
                 constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
-                const int gj = 16 * J + fr;
+                const double tj = lds[C::OFF_YBAR + 16 * J + fr];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int gi = 16 * I + fq + 4 * r;
-                    if (gi < k && gj < k) acc[s][r] -= invN * (lds[C::OFF_YBAR + gi] * lds[C::OFF_YBAR + gj]);
+                    const double ti = lds[C::OFF_YBAR + 16 * I + fq + 4 * r];
+                    const bool on = (J < kI || colv) && (I < kI || fq + 4 * r < kc);
+                    acc[s][r] -= on ? invN * (ti * tj) : 0.0;
                 }
             });
         });
     }
 
+    }
     if (dbg == 3) dump_matrix();
 
-    // ---- phase F: blocked upper Cholesky with the border column riding along
-    bool notpd = false;
-    double* RB = lds + C::OFF_STAGE0;
-    double* MB = lds + C::OFF_STAGE1;
-    double* DG = lds + C::OFF_DIAG;
+    TP_MARK(4);
+    // ---- phase F: blocked upper Cholesky S1 = R'R with the border column riding along.
+    // Block step j: (1) the owner of diagonal tile (j,j) hands it to wave 0 through LDS;
+    // (2) that wave eliminates it (column per lane, 16 pivots, multipliers by v_readlane) together
+    // with 16 identity columns, which gives M = R_jj^-T; (3) every tile of block row j becomes
+    // R_jJ = M A_jJ by MFMA - the accumulator registers ARE the B operand - and goes to LDS;
+    // (4) the trailing tiles are updated from that LDS image by MFMA.  The border column of block row
+    // j turns into y_j = (R^-T b)_j on the way: the forward substitution costs nothing extra.
+    double* RB = lds + C::OFF_STAGE0;          // block row j of R, [16][LDX]
+    double* MB = lds + C::OFF_STAGE1;          // M_j transposed, [NTB][16][16]: MB[j][c][i] = M_j[i][c]
 #pragma nounroll
     for (int j = 0; j < NTB; ++j) {
+        TP_LANE_CONSTANTS();
         const int npiv = (k - 16 * j < 16) ? (k - 16 * j) : 16;
-        // (1) block row j -> LDS
+        double* DG = lds + C::OFF_DIAG + (j & 1) * 256;
+        // (1) diagonal tile -> LDS, row-major
+        wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
+            for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
+                constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
+                if (I == J && I == j) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) DG[(fq + 4 * r) * 16 + fr] = acc[s][r];
+                }
+            });
+        });
+        __syncthreads();
+        // (2) elimination by one wave: lane c < 16 holds column c of the tile, lane 16 + c column c
+        //     of the identity.  Pivots past npiv (last block row only) are made inert by selects, so
+        //     the 16 steps are one straight-line block.
+        // Only wave 0's instantiation carries this code (the window body is specialised per wave).
+        if ((FIX == 0 || FIX < 0) && wv == 0) {
+            const int c16 = lane & 15;
+            double a[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const double x = DG[i * 16 + c16];
+                a[i] = (lane < 16) ? x : ((lane < 32 && c16 == i) ? 1.0 : 0.0);
+            }
+            bool bad = false;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const bool live = p < npiv;
+                double d = readlane_d(a[p], p);
+                bad |= live && !(d > 0.0);
+                d = live ? d : 1.0;
+                const double rinv = rsqrt_nr(d);
+                a[p] *= rinv;
+#pragma unroll
+                for (int i = p + 1; i < 16; ++i) {
+                    // (past npiv the multipliers are zero by construction: row kc only holds
+                    //  products with the zero columns beyond the border, rows after it are zero)
+                    const double sI = readlane_d(a[p], i);
+                    a[i] = fma(-sI, a[p], a[i]);
+                }
+                // keep the scheduler from hoisting the next pivots' v_readlane results (SGPR pairs)
+                // across this point: one pivot's 16 pairs fit the scalar file, all 136 do not
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (lane >= 16 && lane < 32) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) MB[j * 256 + c16 * 16 + i] = a[i];
+            }
+            if (bad && lane == 0) lds[C::OFF_SCAL + 1] = 1.0;
+        }
+        __syncthreads();
+        // (3) block row j: R_jJ = M A_jJ  (A operand M from LDS, B operand = the tile's own registers)
         wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
             for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
                 constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
                 if (I == j) {
+                    d4 rj = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) RB[(fq + 4 * r) * C::LDX + 16 * J + fr] = acc[s][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const double mop = MB[j * 256 + (4 * r + fq) * 16 + fr];   // M[fr][4r + fq]
+                        rj = __builtin_amdgcn_mfma_f64_16x16x4f64(mop, acc[s][r], rj, 0, 0, 0);
+                    }
+                    acc[s] = rj;
+                    if (I != J) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) RB[(fq + 4 * r) * C::LDX + 16 * J + fr] = rj[r];
+                    }
                 }
             });
         });
         __syncthreads();
-        // (2) elimination: lane < 16 holds diagonal-tile column `lane` (every wave, redundantly);
-        //     lanes 16..63 hold the block row's other columns, then 16 identity columns
-        {
-            const int nother = C::KP - 16 * (j + 1);
-            const int oc = 48 * wv + (lane - 16);
-            int colsrc = -1;      // LDS column to load/store, -1: none
-            int ident = -1;       // identity column index, -1: none
-            if (lane < 16) colsrc = 16 * j + lane;
-            else if (oc < nother) colsrc = 16 * (j + 1) + oc;
-            else if (oc < nother + 16) ident = oc - nother;
-            double a[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                double x = 0.0;
-                if (colsrc >= 0) x = RB[i * C::LDX + colsrc];
-                if (ident == i) x = 1.0;
-                a[i] = x;
-            }
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                if (p < npiv) {
-                    const double d = readlane_d(a[p], p);
-                    if (!(d > 0.0)) notpd = true;
-                    const double rinv = 1.0 / sqrt(d);
-                    a[p] *= rinv;
-#pragma unroll
-                    for (int i = p + 1; i < 16; ++i) {
-                        const double sI = readlane_d(a[p], i);
-                        a[i] = fma(-sI, a[p], a[i]);
-                    }
-                }
-            }
-            // a column is written back by the lane that loaded it; the redundantly held diagonal
-            // tile goes to its own image (another wave may still be loading it from RB)
-            if (lane >= 16 && colsrc >= 0) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) RB[i * C::LDX + colsrc] = a[i];
-            }
-            if (lane < 16 && wv == 0) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) DG[i * 16 + lane] = a[i];
-            }
-            if (ident >= 0) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) MB[j * 256 + i * 16 + ident] = a[i];   // M = R_jj^-T, M[i][c]
-            }
-        }
-        __syncthreads();
-        // (3) trailing update A_IJ -= R_jI' R_jJ (I > j) by MFMA; owners of block row j take R back
+        // (4) trailing update A_IJ -= R_jI' R_jJ (I > j) by MFMA from the LDS image of block row j
         {
             const double* lanebase = RB + fq * C::LDX + fr;
             wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
-                constexpr int WV = decltype(wc)::value;
-                mfma_tiles<C, WV, 16, true>(lanebase, acc, [j](int I, int) { return I > j; });
-                for_tiles<C, WV>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
-                    constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
-                    if (I == j) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            acc[s][r] = (I == J) ? DG[(fq + 4 * r) * 16 + fr]
-                                                 : RB[(fq + 4 * r) * C::LDX + 16 * J + fr];
-                    }
-                });
+                mfma_tiles<C, decltype(wc)::value, 16, true>(lanebase, acc, [j](int I, int) { return I > j; });
             });
         }
-        __syncthreads();
+        // no barrier here: RB is rewritten two barriers later, DG alternates between two buffers
     }
 
-    // ---- phase G: y, q1, back substitution
+    TP_MARK(5);
+    // ---- phase G: y, q1, back substitution R w = y with the R tiles still in registers
+    bool notpd = false;
+    double q1 = 0.0;
+    {
+    TP_LANE_CONSTANTS();
+    __syncthreads();      // the last trailing update has read RB; part/yvec/wvec are about to be written
     wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
         for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
-            if (J == kI && fr == kc) {
+            if constexpr (J == kI) {
+                if (fr == kc) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gi = 16 * I + fq + 4 * r;
-                    lds[C::OFF_YVEC + gi] = (gi < k) ? acc[s][r] : 0.0;
+                    for (int r = 0; r < 4; ++r)
+                        lds[C::OFF_YVEC + 16 * I + fq + 4 * r] = (I < kI || fq + 4 * r < kc) ? acc[s][r] : 0.0;
                 }
             }
         });
     });
     for (int c = tid; c < C::KP; c += C::NTHREADS) lds[C::OFF_WVEC + c] = 0.0;
     __syncthreads();
-    double q1 = 0.0;
+    notpd = lds[C::OFF_SCAL + 1] != 0.0;
     for (int i = lane; i < k; i += 64) { const double y = lds[C::OFF_YVEC + i]; q1 = fma(y, y, q1); }
     q1 = wave_sum64(q1);      // every wave computes the same value in the same order
 
+    }
 #pragma nounroll
     for (int Ib = NTB - 1; Ib >= 0; --Ib) {
+        TP_LANE_CONSTANTS();
         const int npiv = (k - 16 * Ib < 16) ? (k - 16 * Ib) : 16;
-        const int solver = Ib % NW;
-        if (wv == solver) {
+        if ((FIX == 0 || FIX < 0) && wv == 0) {
             // z = y_Ib - sum_{J > Ib} R_{Ib,J} w_J   (fixed summation order)
             double z = 0.0;
             if (lane < 16) {
@@ -527,13 +634,12 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
             }
             // w_Ib = R_jj^-1 z = M' z : w[c] = sum_r M[r][c] z[r]
             double wacc = 0.0;
+            const int c16 = lane & 15;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (r < npiv) {
-                    const double zr = readlane_d(z, r);
-                    const double mrc = (lane < 16) ? MB[Ib * 256 + r * 16 + lane] : 0.0;
-                    wacc = fma(mrc, zr, wacc);
-                }
+                double zr = readlane_d(z, r);
+                zr = (r < npiv) ? zr : 0.0;
+                wacc = fma(MB[Ib * 256 + c16 * 16 + r], zr, wacc);
             }
             if (lane < npiv) lds[C::OFF_WVEC + 16 * Ib + lane] = wacc;
         }
@@ -559,8 +665,10 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
         }
     }
 
+    TP_MARK(6);
     // ---- phase H: weights, status, aux
     {
+        TP_LANE_CONSTANTS();
         const double n1 = n0 + (double)A.N;
         const double denom = n1 - q1;
         bool bad = false;
@@ -586,17 +694,30 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
             }
         }
     }
+    TP_MARK(7);
 }
 
 // TP_WAVE_SPECIALISE = 1: the whole window body is instantiated once per wave index (tile
 // coordinates are immediates everywhere, accumulators never cross a dispatch merge);
 // 0: only the tile-touching snippets branch on the wave index.
+// Occupancy the register allocator is asked to keep (wavefronts per SIMD; for NW = 4 that is
+// workgroups per CU).  The serial pivot chain of the factorisation is hidden by windows in flight,
+// not by ILP: on MI355X 4 resident windows per CU with ~270 spilled dwords beat 2 without spills
+// (5.7 vs 4.1 M windows/s at k=100).  Tile counts whose accumulators alone exceed the budget get less.
+#ifdef TP_MIN_WAVES_PER_SIMD
+constexpr int tp_min_waves_for_tiles(int) { return TP_MIN_WAVES_PER_SIMD; }
+#else
+constexpr int tp_min_waves_for_tiles(int nt) {
+    return nt <= 5 ? 4 : nt == 6 ? 2 : nt == 7 ? 4 : nt == 8 ? 3 : nt <= 10 ? 2 : nt <= 12 ? 1 : 2;
+}
+#endif
+
 #ifndef TP_WAVE_SPECIALISE
 #define TP_WAVE_SPECIALISE 1
 #endif
 
 template <int NT, int NW>
-__global__ void __launch_bounds__(64 * NW) posterior_fused_kernel(const tp_kargs_t A) {
+__global__ void __launch_bounds__(64 * NW, tp_min_waves_for_tiles(NT)) posterior_fused_kernel(const tp_kargs_t A) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -639,4 +760,8 @@ int blocks_per_cu() {
 
 // wavefronts per workgroup for a tile count: a block row must fit the elimination lanes
 // (16*NT <= 48*NW) and the tiles must fit the register file
+#ifdef TP_NW_OVERRIDE
+constexpr int tp_waves_for_tiles(int) { return TP_NW_OVERRIDE; }
+#else
 constexpr int tp_waves_for_tiles(int nt) { return nt <= 3 ? 1 : (nt <= 6 ? 2 : (nt <= 12 ? 4 : 8)); }
+#endif

@@ -25,6 +25,7 @@ struct tp_kargs_t {
     double* weights;
     int* status;
     double* aux;
+    long long* stamps;    // diagnostic builds only: [w_count x 8] s_memtime stamps per window
     double* dbg_S1;       // optional [k*k + k]: S1 (or J) and the right-hand side of window dbg_w
     long long dbg_w;
     int dbg_mode;         // 1 prior (S0 | c S0 w0), 2 canonical statistics (T | t), 3 posterior (S1 or J | rhs)

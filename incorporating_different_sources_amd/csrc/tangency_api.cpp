@@ -46,7 +46,7 @@ struct tp_batch_s {
     int64_t W = 0;
     int panel_ld = 0, hf_ld = 0;
     DevBuf panel, start, row_idx, n_rows, col_idx, rf_adj, hf_panel, hf_start, hf_row_idx, hf_count, w0, n0;
-    DevBuf weights, status, aux, dbg, gather_w, gather_s;
+    DevBuf weights, status, aux, dbg, gather_w, gather_s, stamps;
     bool uploaded = false;
 };
 
@@ -126,6 +126,7 @@ tp_kargs_t make_kargs(tp_batch_t b) {
     a.weights = (double*)b->weights.p;
     a.status = (int*)b->status.p;
     a.aux = (double*)b->aux.p;
+    a.stamps = (long long*)b->stamps.p;
     a.dbg_S1 = nullptr;
     a.dbg_w = -1;
     a.w_first = 0;
@@ -289,7 +290,7 @@ int tp_batch_destroy(tp_batch_t b) {
     (void)hipStreamSynchronize(b->h->stream);
     DevBuf* all[] = {&b->panel, &b->start, &b->row_idx, &b->n_rows, &b->col_idx, &b->rf_adj, &b->hf_panel, &b->hf_start,
                      &b->hf_row_idx, &b->hf_count, &b->w0, &b->n0, &b->weights, &b->status, &b->aux, &b->dbg,
-                     &b->gather_w, &b->gather_s};
+                     &b->gather_w, &b->gather_s, &b->stamps};
     for (DevBuf* d : all) release(*d);
     delete b;
     return TP_OK;
@@ -411,6 +412,24 @@ int tp_batch_download_matrix(tp_batch_t b, int64_t w, int what, double* M, doubl
 
 int tp_batch_download_S1(tp_batch_t b, int64_t w, double* S1) {
     return tp_batch_download_matrix(b, w, TP_MATRIX_POSTERIOR, S1, nullptr);
+}
+
+int tp_batch_debug_stamps(tp_batch_t b, int64_t* stamps) {
+    if (!b || !stamps) return TP_ERR_INVALID;
+    tp_handle_t h = b->h;
+#ifdef TP_STAMP
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure(h, b->stamps, sizeof(int64_t) * (size_t)b->W * 8);
+    if (rc != TP_OK) return rc;
+    HIP_TRY(h, hipMemsetAsync(b->stamps.p, 0, sizeof(int64_t) * (size_t)b->W * 8, h->stream));
+    rc = tp_batch_run(b);
+    if (rc != TP_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(stamps, b->stamps.p, sizeof(int64_t) * (size_t)b->W * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return harvest_kernel_time(h);
+#else
+    return fail(h, TP_ERR_UNSUPPORTED, "libtangency was built without TP_STAMP (diagnostic phase stamps)");
+#endif
 }
 
 int tp_posterior_batch(tp_handle_t h, const tp_params_t* p, int64_t W, const tp_inputs_t* in, double* weights,

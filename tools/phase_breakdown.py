@@ -1,0 +1,28 @@
+"""Diagnostic: per-phase share of the fused kernel's per-window time, from in-kernel s_memtime
+stamps.  Needs a TP_STAMP build:  make -C incorporating_different_sources_amd/csrc clean && \
+make -j8 -C incorporating_different_sources_amd/csrc TP_STAMP=1   (rebuild without it afterwards)."""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from incorporating_different_sources_amd import _native, synthetic
+
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+shp = synthetic.config_shapes(cfg)
+inp = synthetic.make_kernel_inputs(shp["k"], shp["N"], W, shp["seed"], hf_days=shp["hf_days"])
+dev = _native.Device(0)
+b = dev.batch("conjugate", shp["k"], shp["N"], shp["n_r"], 5.0, W, shp["m"])
+b.upload(panel=inp["panel"], start=inp["start"], hf_panel=inp["hf_panel"], hf_start=inp["hf_start"], w0=inp["w0"], n0=inp["n0"])
+for _ in range(3):
+    b.run()
+dev.synchronize()
+st = b.debug_stamps()
+print("kernel_ms", dev.last_timing()["kernel_ms"], dev.last_launch())
+d = np.diff(st, axis=1).astype(np.float64)
+names = ["A means", "B hf gram", "C scale", "D daily gram", "F cholesky", "G backsolve", "H output"]
+tot = (st[:, 7] - st[:, 0]).astype(np.float64)
+print(f"per-window wall (s_memtime ticks @100MHz): median {np.median(tot):.0f} ticks = {np.median(tot)*10:.0f} ns")
+for i, n in enumerate(names):
+    print(f"  {n:14s} median {np.median(d[:, i]):8.0f} ticks  share {np.median(d[:, i]) / np.median(tot) * 100:5.1f}%")
+span = st[:, 7].max() - st[:, 0].min()
+print("launch span ticks", span, "=> ms", span / 1e5)
