@@ -144,6 +144,16 @@ def main():
                "sample": f"{reps} x {sample} windows of the same workload (oracle/tangency_oracle.c, OpenMP over "
                          f"windows), {cdt:.2f} s wall"}
 
+    # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside this process);
+    # attached only when the profiled workload is the one benched
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+        if f"k={k}," in pmc["workload"] and f"{W} windows" in pmc["workload"] and args.strategy in pmc["workload"]:
+            traffic = pmc["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
+
     if cp.rank == 0:
         total_windows = W * cp.world * args.steps
         value = total_windows / elapsed
@@ -171,7 +181,8 @@ def main():
                        "strategy": args.strategy, "parallelism": f"windows sharded x{cp.world}",
                        "gather": gather_mode, "seed": shp["seed"]},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": ach_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes)" if traffic else None,
                          "kernel": "posterior_fused_kernel", "kernel_ms": kernel_ms,
                          "alg_flops_per_window": alg_flops_per_window(k, n_r, m, conj),
                          "alg_bytes_per_window": alg_bytes_per_window(k, n_r, m, conj)},

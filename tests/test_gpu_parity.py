@@ -89,3 +89,77 @@ def test_hip_matches_oracle_all_tile_shapes(native, k, N, hf_days, strat):
     np.testing.assert_allclose(wts, ref, rtol=1e-8, atol=1e-10 * max(1.0, scale))
     if strat == "conjugate":
         np.testing.assert_allclose(aux[:, :6], raux[:, :6], rtol=1e-9, atol=1e-12)
+
+
+def test_rccl_gather_world_1(native):
+    """The RCCL leg of the multi-GPU path with a one-rank communicator: ncclCommInitRank, the grouped
+    gather of weights and statuses on the kernel's stream, and the host copy-out."""
+    inp = synthetic.make_kernel_inputs(20, 50, 33, seed=99)
+    dev = native.Device(0)
+    try:
+        dev.comm_init(native.Device.comm_unique_id(), 0, 1)
+        b = dev.batch("conjugate", 20, 50, inp["n_r"], 5.0, 33, inp["m"])
+        b.upload(panel=inp["panel"], start=inp["start"], hf_panel=inp["hf_panel"], hf_start=inp["hf_start"],
+                 w0=inp["w0"], n0=inp["n0"])
+        b.run()
+        wall, sall = b.gather(root=0)
+        w, s, _ = b.download()
+        assert wall.shape == (1, 33, 20) and np.array_equal(wall[0], w) and np.array_equal(sall[0], s)
+        assert dev.last_timing()["gather_ms"] > 0
+        b.close()
+        dev.comm_destroy()
+    finally:
+        dev.close()
+
+
+def test_status_codes(native):
+    """Rank-deficient windows are flagged, not returned as garbage (Appendix B-Q8): Jeffreys with
+    k > n_r - 1 has a singular J; a conjugate window with too few intraday returns likewise."""
+    k, N = 40, 20          # n_r = 19 < k
+    inp = synthetic.make_kernel_inputs(k, N, 3, seed=5)
+    w, status, _ = native.posterior_batch("jeffreys", k, N, 5.0, panel=inp["panel"], start=inp["start"], n_r=inp["n_r"])
+    assert (status != 0).all()
+    # conjugate: rank(S1) <= (n_r) + (m - 1) = 19 + 9 < 40
+    w, status, _ = native.posterior_batch("conjugate", k, N, 5.0, panel=inp["panel"], start=inp["start"], n_r=inp["n_r"],
+                                          hf_panel=inp["hf_panel"], hf_start=inp["hf_start"], m=10, w0=inp["w0"], n0=inp["n0"])
+    assert (status != 0).all()
+
+
+def test_invalid_inputs_are_rejected_on_the_host(native):
+    inp = synthetic.make_kernel_inputs(8, 20, 4, seed=1)
+    bad = inp["start"].copy(); bad[-1] = inp["panel"].shape[0]          # window runs off the panel
+    with pytest.raises(native.TangencyError) as e:
+        native.posterior_batch("jeffreys", 8, 20, 5.0, panel=inp["panel"], start=bad, n_r=inp["n_r"])
+    assert e.value.code == native.TP_ERR_INVALID
+    with pytest.raises(native.TangencyError) as e:                        # k beyond the register-tile kernel
+        native.posterior_batch("jeffreys", 300, 700, 5.0, panel=np.zeros((700, 300)), start=np.zeros(1, np.int64), n_r=699)
+    assert e.value.code == native.TP_ERR_UNSUPPORTED
+    col = np.tile(np.arange(8, dtype=np.int32), (4, 1)); col[0, 0] = 99
+    with pytest.raises(native.TangencyError):
+        native.posterior_batch("jeffreys", 8, 20, 5.0, panel=inp["panel"], start=inp["start"], n_r=inp["n_r"], col_idx=col)
+
+
+def test_row_and_column_index_modes(native):
+    """Explicit row lists (resampled / NaN-dropped windows), per-window row counts, column gathers and
+    the per-row risk-free subtraction give what the dense equivalent gives."""
+    rng = np.random.default_rng(3)
+    k, N, W, Kall = 12, 30, 6, 20
+    inp = synthetic.make_kernel_inputs(Kall, N, W, seed=8)
+    n_r, m = inp["n_r"], inp["m"]
+    cols = np.stack([rng.permutation(Kall)[:k] for _ in range(W)]).astype(np.int32)
+    n_rows = rng.integers(n_r - 5, n_r + 1, size=W).astype(np.int32)
+    rows = np.stack([np.sort(rng.choice(inp["panel"].shape[0], n_r, replace=False)) for _ in range(W)]).astype(np.int32)
+    hf_count = rng.integers(m - 7, m + 1, size=W).astype(np.int32)
+    hf_rows = np.stack([np.sort(rng.choice(inp["hf_panel"].shape[0], m, replace=False)) for _ in range(W)]).astype(np.int32)
+    rf = rng.normal(0, 1e-4, size=(W, n_r))
+    w0 = rng.uniform(0.5, 1.5, size=(W, k)); w0 /= w0.sum(axis=1, keepdims=True)
+    kw = dict(panel=inp["panel"], start=None, n_r=n_r, row_idx=rows, n_rows=n_rows, col_idx=cols, rf_adj=rf,
+              hf_panel=inp["hf_panel"], hf_start=None, hf_row_idx=hf_rows, hf_count=hf_count, m=m, w0=w0, n0=inp["n0"])
+    ref, rstat, raux = oracle.posterior_batch("conjugate", k, N, 5.0, **kw)
+    wts, status, aux = native.posterior_batch("conjugate", k, N, 5.0, **kw)
+    assert (status == rstat).all()
+    np.testing.assert_allclose(wts, ref, rtol=1e-8, atol=1e-10)
+    kwj = dict(panel=inp["panel"], start=None, n_r=n_r, row_idx=rows, n_rows=n_rows, col_idx=cols, rf_adj=rf)
+    refj, _, _ = oracle.posterior_batch("jeffreys", k, N, 5.0, **kwj)
+    wj, sj, _ = native.posterior_batch("jeffreys", k, N, 5.0, **kwj)
+    np.testing.assert_allclose(wj, refj, rtol=1e-7, atol=1e-9)
