@@ -41,3 +41,19 @@ struct tp_launch_info_t { int grid, block, lds_bytes, ntile; };
 int tp_fused_max_assets(void);
 hipError_t tp_fused_launch(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info,
                            int* want_occupancy);
+
+// large-k tiled path (posterior_tiled.hip): k <= tp_tiled_max_assets().  The workspace holds the
+// in-flight windows of one batch: arena [G][KP][KP], rinv [G][NSB][64][64], ybar [G][KP], zc [G][m],
+// scal [G][8] (s, sqrt s, c, q0, n0), flags [G].
+struct tp_tiled_ws_t {
+    double* arena;
+    double* rinv;
+    double* ybar;
+    double* zc;
+    double* scal;
+    int* flags;
+    int KP, NS, NSB;
+};
+int tp_tiled_max_assets(void);
+void tp_tiled_geometry(int k, int* KP, int* NS, int* NSB);
+hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStream_t stream);

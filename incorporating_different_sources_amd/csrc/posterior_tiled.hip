@@ -1,0 +1,433 @@
+// posterior_tiled.hip - large-k path of the posterior (k beyond the register-tile kernel: S&P500-sized
+// and larger universes, BASELINE configs k=500 and k=1000).  gfx950 only.
+//
+// The bordered posterior matrix [[S1, b], [b', .]] (b = c S0 w0 + t) of every in-flight window lives
+// in an HBM arena as a row-major KP x KP square, KP = 64 * NS; work is cut into 64 x 64 super-tiles
+// (4 x 4 f64 MFMA tiles, one workgroup of 4 wavefronts each).  ref:LINE cites
+// /root/reference/src/portfolio_calculations.py.
+//
+//   tiled_prior_kernel   per window: intraday column means (ref:317), z = (Y - ybar) w0, q0 = s z'z,
+//                        c (ref:415-418); leaves ybar and zc = c sqrt(s) z in the workspace
+//   tile64_kernel<GRAM>  one super-tile of  s (Y-ybar)'(Y-ybar) + X'X  in ONE pass over the rows: the
+//                        intraday rows are staged scaled by sqrt(s) with c sqrt(s) z_r in the border
+//                        column, the daily rows with 1 in the border column (ref:180, 222, 333, 358, 489)
+//   tiled_diag_kernel    block step j: Cholesky of the 64 x 64 diagonal block in LDS (upper, R'R) and
+//                        its inverse R_jj^-1 (ref:485's inverse is never formed for the full matrix)
+//   tile64_kernel<TRSM>  R_jJ = R_jj^-T A_jJ as an MFMA product with R_jj^-1 as the k-major A image
+//   tile64_kernel<SYRK>  trailing update A_IJ -= R_jI' R_jJ
+//   tiled_solve_kernel   y = border column (forward substitution happened on the way), q1 = y'y,
+//                        blocked back substitution, weights (ref:572-575, 836 / 849), status, aux
+//
+// Jeffreys (ref:600-606): J = T - t t'/N is applied as a rank-one correction by tile64_kernel<RANK1>
+// after the Gram pass (t is the border column).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "posterior_kernels.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int SB = 64;                 // super-block edge
+constexpr int CH = 16;                 // staged rows per chunk
+constexpr int LDX = 2 * SB + 16;       // LDS row stride of a staged chunk (A cols | B cols), 144 = 16 mod 32
+constexpr int NTHREADS = 256;
+
+enum { MODE_GRAM = 0, MODE_TRSM = 1, MODE_SYRK = 2 };
+
+template <int N>
+__device__ __forceinline__ double dpp_row_ror(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x120 + N, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x120 + N, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rowgroup_sum16(double v) {
+    v += dpp_row_ror<8>(v);
+    v += dpp_row_ror<4>(v);
+    v += dpp_row_ror<2>(v);
+    v += dpp_row_ror<1>(v);
+    return v;
+}
+__device__ __forceinline__ double wave_sum64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// upper-triangle pair p -> (a, b), a <= b < n, row-major
+__device__ __forceinline__ void pair_decode(int p, int n, int& a, int& b) {
+    int i = 0, rem = p;
+    while (rem >= n - i) { rem -= n - i; ++i; }
+    a = i; b = i + rem;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NTHREADS) tiled_prior_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws) {
+    __shared__ double red[NTHREADS];
+    __shared__ double sc[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long wl = blockIdx.x;                 // window inside the batch
+    const long long w = A.w_first + wl;
+    const int k = A.k;
+    const int mm = A.hf_count ? A.hf_count[w] : A.m;
+    const int* cols = A.col_idx ? A.col_idx + w * k : nullptr;
+    const int* ridx = A.hf_row_idx ? A.hf_row_idx + w * (long long)A.m : nullptr;
+    const long long first = A.hf_start ? A.hf_start[w] : 0;
+    double* ybar = ws.ybar + wl * ws.KP;
+    double* zc = ws.zc + wl * (long long)A.m;
+    // column means: thread per column, rows streamed with 8 loads in flight
+    for (int c = tid; c < ws.KP; c += NTHREADS) {
+        double sum = 0.0;
+        if (c < k) {
+            const int gc = cols ? cols[c] : c;
+#pragma unroll 8
+            for (int r = 0; r < mm; ++r) {
+                const long long row = ridx ? (long long)ridx[r] : first + r;
+                sum += A.hf_panel[row * (long long)A.hf_ld + gc];
+            }
+            sum /= (double)mm;
+        }
+        ybar[c] = sum;
+    }
+    __syncthreads();
+    // z_r = (y_r - ybar) . w0 : one wavefront per row
+    double zz = 0.0;
+    for (int r = wv; r < mm; r += 4) {
+        const long long row = ridx ? (long long)ridx[r] : first + r;
+        const double* p = A.hf_panel + row * (long long)A.hf_ld;
+        double z = 0.0;
+        for (int c = lane; c < k; c += 64) z = fma(p[cols ? cols[c] : c] - ybar[c], A.w0[w * k + c], z);
+        z = wave_sum64(z);
+        if (lane == 0) zc[r] = z;
+        zz = fma(z, z, zz);          // identical in every lane of the wave
+    }
+    if (lane == 0) red[wv] = zz;
+    __syncthreads();
+    if (tid == 0) {
+        const double n0 = A.n0[w];
+        const double s = n0 * ((double)mm / ((double)mm - 1.0));
+        const double q0 = s * (red[0] + red[1] + red[2] + red[3]);
+        const double a = n0 + k + 2;
+        const double c = (2 * n0) / (a + sqrt(a * a + 4 * n0 * q0));
+        double* o = ws.scal + wl * 8;
+        o[0] = s; o[1] = sqrt(s); o[2] = c; o[3] = q0; o[4] = n0;
+        sc[0] = c * sqrt(s);
+    }
+    __syncthreads();
+    const double f = sc[0];
+    for (int r = tid; r < mm; r += NTHREADS) zc[r] *= f;    // border-column entries of the staged intraday rows
+}
+
+// ------------------------------------------------------------------------------------------------
+// One 64 x 64 super-tile: D[i][j] (+/-)= sum_r Aimg[r][i] Bimg[r][j] over the rows the mode provides.
+template <int MODE>
+__global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws, const int j) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * CH * LDX];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const long long wl = blockIdx.x;
+    const long long w = A.w_first + wl;
+    const int k = A.k, KP = ws.KP, NS = ws.NS;
+    double* M = ws.arena + wl * (long long)KP * KP;
+
+    int SI, SJ;
+    if (MODE == MODE_GRAM) pair_decode(blockIdx.y, NS, SI, SJ);
+    else if (MODE == MODE_TRSM) { SI = j; SJ = j + 1 + blockIdx.y; }
+    else { int a, b; pair_decode(blockIdx.y, NS - 1 - j, a, b); SI = j + 1 + a; SJ = j + 1 + b; }
+
+    // row sources
+    const int* cols = A.col_idx ? A.col_idx + w * k : nullptr;
+    int mm = 0, nr = 0, nrows = SB;
+    const int* hridx = nullptr; const int* dridx = nullptr;
+    long long hfirst = 0, dfirst = 0;
+    const double* rf = nullptr;
+    double sqs = 0.0;
+    const double* ybar = ws.ybar + wl * KP;
+    const double* zc = ws.zc + wl * (long long)A.m;
+    if (MODE == MODE_GRAM) {
+        if (A.strategy == 0) {
+            mm = A.hf_count ? A.hf_count[w] : A.m;
+            hridx = A.hf_row_idx ? A.hf_row_idx + w * (long long)A.m : nullptr;
+            hfirst = A.hf_start ? A.hf_start[w] : 0;
+            sqs = ws.scal[wl * 8 + 1];
+        }
+        nr = A.n_rows ? A.n_rows[w] : A.n_r;
+        dridx = A.row_idx ? A.row_idx + w * (long long)A.n_r : nullptr;
+        dfirst = A.start ? A.start[w] : 0;
+        rf = A.rf_adj ? A.rf_adj + w * (long long)A.n_r : nullptr;
+        nrows = mm + nr;
+    }
+    const double* rinv = ws.rinv + (wl * ws.NSB + j) * (long long)(SB * SB);
+
+    // value of staged element (row r, half h = 0: A columns / 1: B columns, local column c)
+    auto fetch = [&](int r, int h, int c) -> double {
+        if (MODE == MODE_GRAM) {
+            const int gc = 64 * (h ? SJ : SI) + c;
+            const bool hf = r < mm;
+            if (gc < k) {
+                const int pc = cols ? cols[gc] : gc;
+                if (hf) {
+                    const long long row = hridx ? (long long)hridx[r] : hfirst + r;
+                    return sqs * (A.hf_panel[row * (long long)A.hf_ld + pc] - ybar[gc]);
+                }
+                const int rd = r - mm;
+                const long long row = dridx ? (long long)dridx[rd] : dfirst + rd;
+                return A.panel[row * (long long)A.panel_ld + pc] - (rf ? rf[rd] : 0.0);
+            }
+            if (gc == k) return hf ? zc[r] : 1.0;
+            return 0.0;
+        } else if (MODE == MODE_TRSM) {
+            if (h == 0) return rinv[r * SB + c];                              // k-major image of R_jj^-T
+            return M[(long long)(64 * j + r) * KP + 64 * SJ + c];
+        } else {
+            return M[(long long)(64 * j + r) * KP + 64 * (h ? SJ : SI) + c];
+        }
+    };
+
+    d4 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
+    if (MODE == MODE_SYRK) {           // C - R'R: start from C
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[b][r] = M[(long long)(64 * SI + 16 * wv + fq + 4 * r) * KP + 64 * SJ + 16 * b + fr];
+    }
+
+    const int nchunks = (nrows + CH - 1) / CH;
+    const int srow = tid >> 4, cb = tid & 15;
+    double v[8];
+    auto load = [&](int ch) {
+        const int r = ch * CH + srow;
+        const bool rv = r < nrows;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = rv ? fetch(r, i >> 2, cb + 16 * (i & 3)) : 0.0;
+    };
+    auto store = [&](double* buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) buf[srow * LDX + 64 * (i >> 2) + cb + 16 * (i & 3)] = v[i];
+    };
+    if (nchunks > 0) { load(0); store(lds); }
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        double* cur = lds + (ch & 1) * CH * LDX;
+        double* nxt = lds + ((ch + 1) & 1) * CH * LDX;
+        const bool more = ch + 1 < nchunks;
+        if (more) load(ch + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const double* lb = cur + fq * LDX + fr;
+#pragma unroll
+        for (int s4 = 0; s4 < CH / 4; ++s4) {
+            double a = lb[4 * s4 * LDX + 16 * wv];
+            if (MODE == MODE_SYRK) a = -a;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, lb[4 * s4 * LDX + 64 + 16 * b], acc[b], 0, 0, 0);
+        }
+        if (more) store(nxt);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            M[(long long)(64 * SI + 16 * wv + fq + 4 * r) * KP + 64 * SJ + 16 * b + fr] = acc[b][r];
+}
+
+// Jeffreys: J = T - t t'/N on one super-tile (t = border column k); rows/cols >= k untouched.
+__global__ void __launch_bounds__(NTHREADS) tiled_rank1_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws) {
+    const int tid = threadIdx.x;
+    const long long wl = blockIdx.x;
+    const int k = A.k, KP = ws.KP, NS = ws.NS;
+    double* M = ws.arena + wl * (long long)KP * KP;
+    int SI, SJ;
+    pair_decode(blockIdx.y, NS, SI, SJ);
+    const double invN = 1.0 / (double)A.N;
+    for (int e = tid; e < SB * SB; e += NTHREADS) {
+        const int gi = 64 * SI + (e >> 6), gj = 64 * SJ + (e & 63);
+        if (gi < k && gj < k) {
+            const double ti = M[(long long)gi * KP + k], tj = M[(long long)gj * KP + k];
+            M[(long long)gi * KP + gj] -= invN * (ti * tj);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block step j: upper Cholesky of the 64 x 64 diagonal block in LDS and R_jj^-1.  Rows >= npiv (the
+// last block only: border row and padding) behave as identity rows.
+__global__ void __launch_bounds__(NTHREADS) tiled_diag_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws, const int j) {
+    constexpr int LD = SB + 1;
+    __shared__ double Ab[SB * LD];
+    __shared__ double Rv[SB * LD];
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    const long long wl = blockIdx.x;
+    const int k = A.k, KP = ws.KP;
+    double* M = ws.arena + wl * (long long)KP * KP;
+    const int npiv = (k - 64 * j < SB) ? (k - 64 * j) : SB;
+    if (tid == 0) bad = 0;
+    for (int e = tid; e < SB * SB; e += NTHREADS) {
+        const int i = e >> 6, c = e & 63;
+        Ab[i * LD + c] = M[(long long)(64 * j + i) * KP + 64 * j + c];
+    }
+    __syncthreads();
+    for (int p = 0; p < npiv; ++p) {
+        const double d = Ab[p * LD + p];
+        if (!(d > 0.0) && tid == 0) bad = 1;
+        const double rinv = 1.0 / sqrt(d);
+        __syncthreads();                       // everyone has read d before row p is rescaled
+        if (tid >= p && tid < SB) Ab[p * LD + tid] *= rinv;
+        __syncthreads();
+        // trailing update of rows p+1 .. npiv-1, all columns c >= i (the border column included)
+        const int nrow = npiv - 1 - p;
+        for (int e = tid; e < nrow * SB; e += NTHREADS) {
+            const int i = p + 1 + e / SB, c = e % SB;
+            if (c >= i) Ab[i * LD + c] = fma(-Ab[p * LD + i], Ab[p * LD + c], Ab[i * LD + c]);
+        }
+        __syncthreads();
+    }
+    // R_jj^-1 (upper): thread c solves column c by back substitution; rows >= npiv are identity rows
+    if (tid < SB) {
+        const int c = tid;
+        for (int i = SB - 1; i >= 0; --i) {
+            double x;
+            if (i > c) x = 0.0;
+            else if (i >= npiv) x = (i == c) ? 1.0 : 0.0;
+            else {
+                double s = (i == c) ? 1.0 : 0.0;
+                const int lim = (c < npiv - 1) ? c : npiv - 1;
+                for (int q = i + 1; q <= lim; ++q) s = fma(-Ab[i * LD + q], Rv[q * LD + c], s);
+                x = s / Ab[i * LD + i];
+            }
+            Rv[i * LD + c] = x;
+        }
+    }
+    __syncthreads();
+    double* rinv = ws.rinv + (wl * ws.NSB + j) * (long long)(SB * SB);
+    for (int e = tid; e < SB * SB; e += NTHREADS) {
+        const int i = e >> 6, c = e & 63;
+        rinv[e] = Rv[i * LD + c];
+        // factored rows back to the arena (upper part; the border column of the last block is y)
+        if (i < npiv && c >= i) M[(long long)(64 * j + i) * KP + 64 * j + c] = Ab[i * LD + c];
+    }
+    if (tid == 0 && bad) ws.flags[wl] = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NTHREADS) tiled_solve_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];     // wvec[KP] | zv[64]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long wl = blockIdx.x;
+    const long long w = A.w_first + wl;
+    const int k = A.k, KP = ws.KP, NSB = ws.NSB;
+    const double* M = ws.arena + wl * (long long)KP * KP;
+    double* wvec = sm;
+    double* zv = sm + KP;
+    __shared__ double qs[4];
+    __shared__ int anybad;
+    if (tid == 0) anybad = 0;
+    for (int c = tid; c < KP; c += NTHREADS) wvec[c] = 0.0;
+    // q1 = y'y, y = border column
+    double q = 0.0;
+    for (int i = tid; i < k; i += NTHREADS) { const double y = M[(long long)i * KP + k]; q = fma(y, y, q); }
+    q = wave_sum64(q);
+    if (lane == 0) qs[wv] = q;
+    __syncthreads();
+    const double q1 = qs[0] + qs[1] + qs[2] + qs[3];
+
+    const int srow = tid >> 4, cb = tid & 15;      // 16 lanes per row, 16 rows per pass
+    for (int Jb = NSB - 1; Jb >= 0; --Jb) {
+        const int npiv = (k - 64 * Jb < SB) ? (k - 64 * Jb) : SB;
+        // z = y_Jb - sum_{c >= 64 (Jb+1)} R[row][c] w[c]
+        for (int ps = 0; ps < 4; ++ps) {
+            const int i = 16 * ps + srow;                 // local row
+            const long long gi = 64 * Jb + i;
+            double s = 0.0;
+            if (i < npiv)
+                for (int c = 64 * (Jb + 1) + cb; c < k; c += 16) s = fma(M[gi * KP + c], wvec[c], s);
+            s = rowgroup_sum16(s);
+            if (cb == 0) zv[i] = (i < npiv) ? M[gi * KP + k] - s : 0.0;
+        }
+        __syncthreads();
+        // w_Jb = R_jj^-1 z
+        const double* rinv = ws.rinv + (wl * ws.NSB + Jb) * (long long)(SB * SB);
+        for (int ps = 0; ps < 4; ++ps) {
+            const int i = 16 * ps + srow;
+            double s = 0.0;
+            for (int c = cb; c < SB; c += 16) s = fma(rinv[i * SB + c], zv[c], s);
+            s = rowgroup_sum16(s);
+            if (cb == 0 && i < npiv) wvec[64 * Jb + i] = s;
+        }
+        __syncthreads();
+    }
+    const bool conj = A.strategy == 0;
+    const double n0 = conj ? ws.scal[wl * 8 + 4] : 0.0;
+    const double n1 = n0 + (double)A.N;
+    const double denom = n1 - q1;
+    bool bad = false;
+    for (int i = tid; i < k; i += NTHREADS) {
+        const double wi = wvec[i];
+        const double out = conj ? 1.0 / A.gamma * ((n1 + k + 2) * wi / denom) : 1.0 / A.gamma * wi;
+        A.weights[w * k + i] = out;
+        if (!isfinite(out)) bad = true;
+    }
+    if (bad) anybad = 1;
+    __syncthreads();
+    if (tid == 0) {
+        int st = TP_KSTATUS_OK;
+        if (ws.flags[wl]) st = TP_KSTATUS_NOT_PD;
+        else if (anybad) st = TP_KSTATUS_NONFINITE;
+        else if (conj && !(denom > 0.0)) st = TP_KSTATUS_BAD_DENOM;
+        A.status[w] = st;
+        if (A.aux) {
+            double* ax = A.aux + w * 8;
+            ax[0] = n0; ax[1] = conj ? n1 : 0.0; ax[2] = conj ? ws.scal[wl * 8 + 2] : 0.0;
+            ax[3] = conj ? ws.scal[wl * 8 + 3] : 0.0; ax[4] = q1; ax[5] = conj ? denom : 0.0; ax[6] = 0.0; ax[7] = 0.0;
+        }
+    }
+}
+
+// rows >= k of the bordered matrix are never pivots: clear the border ROW (it holds 1'X etc.) so the
+// last diagonal block sees zero rows there; also zero the not-positive-definite flags
+__global__ void __launch_bounds__(NTHREADS) tiled_clear_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws) {
+    const long long wl = blockIdx.x;
+    const int k = A.k, KP = ws.KP;
+    double* M = ws.arena + wl * (long long)KP * KP;
+    for (int e = threadIdx.x; e < (KP - k) * KP; e += NTHREADS) M[(long long)k * KP + e] = 0.0;
+    if (threadIdx.x == 0) ws.flags[wl] = 0;
+}
+
+}  // namespace
+
+int tp_tiled_max_assets(void) { return 64 * 32 - 1; }
+
+void tp_tiled_geometry(int k, int* KP, int* NS, int* NSB) {
+    const int ns = (k + 1 + SB - 1) / SB;
+    *NS = ns; *KP = ns * SB; *NSB = (k + SB - 1) / SB;
+}
+
+// Whole pipeline for windows [a.w_first, a.w_first + a.w_count) (a.w_count <= ws capacity), on `stream`.
+hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStream_t stream) {
+    const int G = (int)a.w_count;
+    if (G <= 0) return hipSuccess;
+    const int NS = ws.NS, NSB = ws.NSB;
+    const bool conj = a.strategy == 0;
+    if (conj) hipLaunchKernelGGL(tiled_prior_kernel, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
+    hipLaunchKernelGGL(tile64_kernel<MODE_GRAM>, dim3(G, NS * (NS + 1) / 2), dim3(NTHREADS), 0, stream, a, ws, 0);
+    if (!conj) hipLaunchKernelGGL(tiled_rank1_kernel, dim3(G, NS * (NS + 1) / 2), dim3(NTHREADS), 0, stream, a, ws);
+    hipLaunchKernelGGL(tiled_clear_kernel, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
+    for (int j = 0; j < NSB; ++j) {
+        hipLaunchKernelGGL(tiled_diag_kernel, dim3(G), dim3(NTHREADS), 0, stream, a, ws, j);
+        const int T = NS - 1 - j;
+        if (T > 0) {
+            hipLaunchKernelGGL(tile64_kernel<MODE_TRSM>, dim3(G, T), dim3(NTHREADS), 0, stream, a, ws, j);
+            hipLaunchKernelGGL(tile64_kernel<MODE_SYRK>, dim3(G, T * (T + 1) / 2), dim3(NTHREADS), 0, stream, a, ws, j);
+        }
+    }
+    const size_t smem = sizeof(double) * (size_t)(ws.KP + SB);
+    hipLaunchKernelGGL(tiled_solve_kernel, dim3(G), dim3(NTHREADS), smem, stream, a, ws);
+    return hipGetLastError();
+}

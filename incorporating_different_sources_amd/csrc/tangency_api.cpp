@@ -47,6 +47,8 @@ struct tp_batch_s {
     int panel_ld = 0, hf_ld = 0;
     DevBuf panel, start, row_idx, n_rows, col_idx, rf_adj, hf_panel, hf_start, hf_row_idx, hf_count, w0, n0;
     DevBuf weights, status, aux, dbg, gather_w, gather_s, stamps;
+    DevBuf t_arena, t_rinv, t_ybar, t_zc, t_scal, t_flags;   // large-k path workspace
+    int64_t tiled_capacity = 0;                               // windows in flight per sub-batch
     bool uploaded = false;
 };
 
@@ -104,7 +106,7 @@ int check_params(tp_handle_t h, const tp_params_t* p, int64_t W) {
         return fail(h, TP_ERR_INVALID, "conjugate prior needs m >= 2 intraday returns (m=%d)", p->m);
     if (!(p->gamma > 0.0) && !(p->gamma < 0.0)) return fail(h, TP_ERR_INVALID, "gamma must be non-zero");
     if (p->k > tp_max_assets())
-        return fail(h, TP_ERR_UNSUPPORTED, "k=%d exceeds the register-tile kernel's limit %d", p->k, tp_max_assets());
+        return fail(h, TP_ERR_UNSUPPORTED, "k=%d exceeds the largest supported universe %d", p->k, tp_max_assets());
     return TP_OK;
 }
 
@@ -191,13 +193,57 @@ int validate_inputs(tp_handle_t h, const tp_params_t& p, int64_t W, const tp_inp
     return TP_OK;
 }
 
+// workspace of the large-k path, sized for as many in-flight windows as ~6 GiB allow
+int ensure_tiled_ws(tp_batch_t b, tp_tiled_ws_t* ws) {
+    tp_handle_t h = b->h;
+    int KP, NS, NSB;
+    tp_tiled_geometry(b->p.k, &KP, &NS, &NSB);
+    const size_t per_window = sizeof(double) * ((size_t)KP * KP + (size_t)NSB * 64 * 64 + KP + (size_t)b->p.m + 8) + 4;
+    int64_t G = (int64_t)((6ULL << 30) / per_window);
+    if (G < 1) G = 1;
+    if (G > b->W) G = b->W;
+    if (G > 65535) G = 65535;
+    if (b->tiled_capacity < G) {
+        int rc = ensure(h, b->t_arena, sizeof(double) * (size_t)G * KP * KP);
+        if (rc == TP_OK) rc = ensure(h, b->t_rinv, sizeof(double) * (size_t)G * NSB * 64 * 64);
+        if (rc == TP_OK) rc = ensure(h, b->t_ybar, sizeof(double) * (size_t)G * KP);
+        if (rc == TP_OK) rc = ensure(h, b->t_zc, sizeof(double) * (size_t)G * (b->p.m > 0 ? b->p.m : 1));
+        if (rc == TP_OK) rc = ensure(h, b->t_scal, sizeof(double) * (size_t)G * 8);
+        if (rc == TP_OK) rc = ensure(h, b->t_flags, sizeof(int) * (size_t)G);
+        if (rc != TP_OK) return rc;
+        b->tiled_capacity = G;
+    }
+    ws->arena = (double*)b->t_arena.p; ws->rinv = (double*)b->t_rinv.p; ws->ybar = (double*)b->t_ybar.p;
+    ws->zc = (double*)b->t_zc.p; ws->scal = (double*)b->t_scal.p; ws->flags = (int*)b->t_flags.p;
+    ws->KP = KP; ws->NS = NS; ws->NSB = NSB;
+    return TP_OK;
+}
+
 int launch(tp_batch_t b, const tp_kargs_t& a, int64_t count, bool timed) {
     tp_handle_t h = b->h;
     if (count <= 0) return TP_OK;
     if (count > 0x7fffffffLL) return fail(h, TP_ERR_INVALID, "too many windows in one launch");
+    if (a.k <= tp_fused_max_assets()) {
+        if (timed) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+        hipError_t e = tp_fused_launch(a, (int)count, h->stream, &h->last_launch, nullptr);
+        if (e != hipSuccess) return fail(h, TP_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+        if (timed) { HIP_TRY(h, hipEventRecord(h->ev1, h->stream)); h->kernel_timed = true; }
+        return TP_OK;
+    }
+    // large-k path: sub-batches of in-flight windows through the tiled pipeline
+    if (a.dbg_S1 != nullptr) return fail(h, TP_ERR_UNSUPPORTED, "matrix read-back is not available on the large-k path");
+    tp_tiled_ws_t ws;
+    int rc = ensure_tiled_ws(b, &ws);
+    if (rc != TP_OK) return rc;
     if (timed) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    hipError_t e = tp_fused_launch(a, (int)count, h->stream, &h->last_launch, nullptr);
-    if (e != hipSuccess) return fail(h, TP_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    for (int64_t w0 = 0; w0 < count; w0 += b->tiled_capacity) {
+        tp_kargs_t sub = a;
+        sub.w_first = a.w_first + w0;
+        sub.w_count = (count - w0 < b->tiled_capacity) ? (count - w0) : b->tiled_capacity;
+        hipError_t e = tp_tiled_launch(sub, ws, h->stream);
+        if (e != hipSuccess) return fail(h, TP_ERR_HIP, "tiled pipeline launch failed: %s", hipGetErrorString(e));
+    }
+    h->last_launch = tp_launch_info_t{(int)(count < b->tiled_capacity ? count : b->tiled_capacity), 256, 36864, ws.NS * 4};
     if (timed) { HIP_TRY(h, hipEventRecord(h->ev1, h->stream)); h->kernel_timed = true; }
     return TP_OK;
 }
@@ -206,9 +252,9 @@ int launch(tp_batch_t b, const tp_kargs_t& a, int64_t count, bool timed) {
 
 extern "C" {
 
-const char* tp_version(void) { return "tangency-posterior 0.1.0 (gfx950, fp64 MFMA register-tile kernel)"; }
+const char* tp_version(void) { return "tangency-posterior 0.2.0 (gfx950, fp64 MFMA: register-tile kernel k<=239, tiled pipeline k<=2047)"; }
 
-int tp_max_assets(void) { return tp_fused_max_assets(); }
+int tp_max_assets(void) { return tp_tiled_max_assets(); }
 
 const char* tp_last_error(tp_handle_t h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -290,7 +336,8 @@ int tp_batch_destroy(tp_batch_t b) {
     (void)hipStreamSynchronize(b->h->stream);
     DevBuf* all[] = {&b->panel, &b->start, &b->row_idx, &b->n_rows, &b->col_idx, &b->rf_adj, &b->hf_panel, &b->hf_start,
                      &b->hf_row_idx, &b->hf_count, &b->w0, &b->n0, &b->weights, &b->status, &b->aux, &b->dbg,
-                     &b->gather_w, &b->gather_s, &b->stamps};
+                     &b->gather_w, &b->gather_s, &b->stamps, &b->t_arena, &b->t_rinv, &b->t_ybar, &b->t_zc,
+                     &b->t_scal, &b->t_flags};
     for (DevBuf* d : all) release(*d);
     delete b;
     return TP_OK;

@@ -131,8 +131,8 @@ def test_invalid_inputs_are_rejected_on_the_host(native):
     with pytest.raises(native.TangencyError) as e:
         native.posterior_batch("jeffreys", 8, 20, 5.0, panel=inp["panel"], start=bad, n_r=inp["n_r"])
     assert e.value.code == native.TP_ERR_INVALID
-    with pytest.raises(native.TangencyError) as e:                        # k beyond the register-tile kernel
-        native.posterior_batch("jeffreys", 300, 700, 5.0, panel=np.zeros((700, 300)), start=np.zeros(1, np.int64), n_r=699)
+    with pytest.raises(native.TangencyError) as e:                        # k beyond the largest supported universe
+        native.posterior_batch("jeffreys", 2100, 30, 5.0, panel=np.zeros((30, 2100)), start=np.zeros(1, np.int64), n_r=29)
     assert e.value.code == native.TP_ERR_UNSUPPORTED
     col = np.tile(np.arange(8, dtype=np.int32), (4, 1)); col[0, 0] = 99
     with pytest.raises(native.TangencyError):
@@ -163,3 +163,48 @@ def test_row_and_column_index_modes(native):
     refj, _, _ = oracle.posterior_batch("jeffreys", k, N, 5.0, **kwj)
     wj, sj, _ = native.posterior_batch("jeffreys", k, N, 5.0, **kwj)
     np.testing.assert_allclose(wj, refj, rtol=1e-7, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------
+# large-k path (tiled pipeline, k >= 240): BASELINE configs[2] (k=500) and configs[4] (k=1000)
+@pytest.mark.parametrize("name", ["single_k500_n250", "single_k1000_n500"])
+@pytest.mark.parametrize("strat", ["conjugate_hf_vix_vw", "conjugate_hf_vix_ew"])
+def test_tiled_path_matches_reference_golden(native, name, strat):
+    """Outputs-only goldens of the unmodified reference at S&P500-sized universes; inputs regenerated
+    from the seed and pushed through the same price round trip the reference saw."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    k, N, hf_days, seed = int(g["k"]), int(g["N"]), int(g["hf_days"]), int(g["seed"])
+    inp = synthetic.make_kernel_inputs(k, N, 1, seed, hf_days=hf_days)
+    n_r, m = inp["n_r"], inp["m"]
+    P = 100.0 * np.exp(np.concatenate([np.zeros((1, k)), np.cumsum(inp["panel"][:n_r], axis=0)]))
+    X = oracle.excess_log_returns_from_prices(P)
+    H = 50.0 * np.exp(np.concatenate([np.zeros((1, k)), np.cumsum(inp["hf_panel"][:m], axis=0)]))
+    Y = oracle.excess_log_returns_from_prices(H)
+    order = g[f"w0_{strat}_order"].astype(np.int32)
+    wts, status, aux = native.posterior_batch(
+        "conjugate", k, N, 5.0, panel=X, start=np.zeros(1, np.int64), n_r=n_r, hf_panel=Y,
+        hf_start=np.zeros(1, np.int64), m=m, w0=g[f"w0_{strat}_w0"][None, :],
+        n0=np.array([float(g[f"w0_{strat}_n0"])]), col_idx=order[None, :])
+    assert status[0] == 0
+    np.testing.assert_allclose(wts[0], g[f"w0_{strat}_weights"], rtol=1e-8, atol=1e-10)
+    assert aux[0, 2] == pytest.approx(float(g[f"w0_{strat}_c"]), rel=1e-11)
+    assert aux[0, 4] == pytest.approx(float(g[f"w0_{strat}_q1"]), rel=1e-8)
+
+
+@pytest.mark.parametrize("k,N,hf_days,strat", [
+    (240, 300, 2, "conjugate"), (255, 300, 2, "conjugate"), (256, 300, 2, "conjugate"), (300, 700, 1, "jeffreys"),
+    (319, 250, 3, "conjugate"), (320, 250, 3, "conjugate"), (500, 250, 5, "conjugate"), (511, 260, 5, "conjugate"),
+    (512, 1100, 1, "jeffreys"), (640, 400, 6, "conjugate"), (1000, 500, 22, "conjugate")])
+def test_tiled_path_matches_oracle(native, k, N, hf_days, strat):
+    W = 3
+    inp = synthetic.make_kernel_inputs(k, N, W, seed=880000 + k, hf_days=hf_days)
+    kw = dict(panel=inp["panel"], start=inp["start"], n_r=inp["n_r"])
+    if strat == "conjugate":
+        kw.update(hf_panel=inp["hf_panel"], hf_start=inp["hf_start"], m=inp["m"], w0=inp["w0"], n0=inp["n0"])
+    ref, rstat, raux = oracle.posterior_batch_c(strat, k, N, 5.0, **kw)
+    wts, status, aux = native.posterior_batch(strat, k, N, 5.0, **kw)
+    assert (status == rstat).all()
+    scale = max(1.0, np.abs(ref).max())
+    np.testing.assert_allclose(wts, ref, rtol=1e-7, atol=1e-10 * scale)
+    if strat == "conjugate":
+        np.testing.assert_allclose(aux[:, :6], raux[:, :6], rtol=1e-8, atol=1e-12)
