@@ -39,6 +39,12 @@ def alg_flops_per_window(k, n_r, m, conj=True):
 
 
 def main():
+    # Libraries underneath (gloo, RCCL) print banners on the C-level stdout.  The contract is ONE JSON
+    # line on stdout, so everything else is routed to stderr and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -63,7 +69,8 @@ def main():
     # rank r owns its own windows (weak scaling): an independent synthetic panel per rank
     inp = synthetic.make_kernel_inputs(k, N, W, seed=shp["seed"] + 1000 * cp.rank, hf_days=shp["hf_days"])
 
-    dev = _native.Device(cp.local_rank)
+    # one GPU per rank; on a box with fewer GPUs than ranks (rehearsals) ranks wrap around
+    dev = _native.Device(cp.local_rank % max(1, _native.device_count()))
     gather_mode = "none"
     if cp.world > 1:
         try:
@@ -183,7 +190,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes)" if traffic else None,
-                         "kernel": "posterior_fused_kernel", "kernel_ms": kernel_ms,
+                         "kernel": "posterior_fused_kernel" if k <= 239 else "tiled pipeline (tile64_kernel<GRAM/TRSM/SYRK> + diag + solve)",
+                         "kernel_ms": kernel_ms,
                          "alg_flops_per_window": alg_flops_per_window(k, n_r, m, conj),
                          "alg_bytes_per_window": alg_bytes_per_window(k, n_r, m, conj)},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -196,7 +204,8 @@ def main():
             "h2d_ms": h2d_ms, "d2h_ms": d2h_ms, "gather_ms": tim["gather_ms"] if cp.world > 1 else None,
             "host": {"cpus": len(os.sched_getaffinity(0))},
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     batch.close()
     dev.close()
     cp.close()

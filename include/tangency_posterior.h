@@ -96,6 +96,8 @@ typedef struct tp_inputs {
 const char* tp_version(void);
 /* largest portfolio_spec["size"] the built kernels cover */
 int tp_max_assets(void);
+/* number of visible HIP devices (0 when there is none: tp_create will then fail) */
+int tp_device_count(void);
 
 /* Contexts.  tp_create binds device `device_id`, creates a stream and timing events.
  * Replaces: nothing in the reference (it has no device); corresponds to process start-up. */

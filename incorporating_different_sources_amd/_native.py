@@ -29,7 +29,7 @@ UNIQUE_ID_BYTES = 128
 
 # every symbol include/tangency_posterior.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTS = [
-    "tp_version", "tp_max_assets", "tp_create", "tp_destroy", "tp_last_error", "tp_device_info",
+    "tp_version", "tp_max_assets", "tp_device_count", "tp_create", "tp_destroy", "tp_last_error", "tp_device_info",
     "tp_batch_create", "tp_batch_upload", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1", "tp_batch_download_matrix", "tp_batch_debug_stamps",
     "tp_batch_destroy", "tp_posterior_batch", "tp_synchronize", "tp_last_timing", "tp_region_begin",
     "tp_region_end", "tp_last_launch", "tp_comm_unique_id", "tp_comm_init", "tp_comm_destroy",
@@ -105,6 +105,10 @@ def version() -> str:
 
 def max_assets() -> int:
     return int(lib.tp_max_assets())
+
+
+def device_count() -> int:
+    return int(lib.tp_device_count())
 
 
 def _ptr(a, ct):

@@ -256,6 +256,12 @@ const char* tp_version(void) { return "tangency-posterior 0.2.0 (gfx950, fp64 MF
 
 int tp_max_assets(void) { return tp_tiled_max_assets(); }
 
+int tp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
 const char* tp_last_error(tp_handle_t h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int tp_create(int device_id, tp_handle_t* out) {
