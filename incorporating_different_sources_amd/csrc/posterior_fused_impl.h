@@ -47,8 +47,10 @@ constexpr int tp_kstep_unroll = TP_KSTEP_UNROLL;
 // Diagnostic build only (make TP_STAMP=1): per-window s_memtime stamps at the phase boundaries, written
 // to a buffer of their own (never into an output).  The product build compiles none of this.
 #ifdef TP_STAMP
-#define TP_MARK(slot) do { if (A.stamps && (tid0 == 0)) A.stamps[(w - A.w_first) * 8 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define TP_LOOPSTAMP_PTR (A.stamps ? A.stamps + (w - A.w_first) * 24 + 8 : nullptr)
+#define TP_MARK(slot) do { if (A.stamps && (tid0 == 0)) A.stamps[(w - A.w_first) * 24 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define TP_LOOPSTAMP_PTR nullptr
 #define TP_MARK(slot) do { } while (0)
 #endif
 
@@ -200,29 +202,41 @@ struct RowSource {
     int count;              // rows of this window
 };
 
+// Issue the global loads of one staged chunk: RAW values only.  Nothing here may consume a loaded
+// value (no subtraction, no select): any use would make the compiler wait for the loads right here
+// and the prefetch under the MFMA block would be lost (it was: 4.4 k cycles per chunk).  Masking,
+// centring and the risk-free subtraction happen in store_chunk, after the MFMAs.
 template <class C, bool HF>
 __device__ __forceinline__ void load_chunk(const RowSource& src, const int* __restrict__ cols, int k, int chunk,
-                                           int tid, double (&v)[C::PASSES][C::NT]) {
+                                           int tid, double (&v)[C::PASSES][C::NT], double (&sub)[C::PASSES]) {
     const int cb = tid & 15;
-#pragma unroll
-    for (int ps = 0; ps < C::PASSES; ++ps) {
-        const int r = chunk * C::CH + ps * C::ROWS_PER_PASS + (tid >> 4);
-        const bool rv = r < src.count;
-        const int rc = rv ? r : src.count - 1;            // clamp (count >= 1 is validated on the host)
-        const long long row = src.ridx ? (long long)src.ridx[rc] : src.first + rc;
-        double sub = 0.0;
-        if (!HF && src.sub_row) sub = src.sub_row[rc];
-        const double* p = src.base + row * (long long)src.ld;
+    // Column offsets first, under ONE uniform branch: with the select inside the load loop the
+    // compiler merged the two paths per element and put an s_waitcnt vmcnt(0) in front of every data
+    // load (7 serialised L2 round trips per chunk).
+    int ci[C::NT];
+    if (cols) {
 #pragma unroll
         for (int i = 0; i < C::NT; ++i) {
             const int c = cb + 16 * i;
-            // k >= 16 (NT-1): only the last 16-column group can hold columns >= k.  Loads are
-            // unconditional on clamped addresses and masked by selects (no divergent branches).
-            const bool cv = (i < C::NT - 1) || (c < k);
-            const int cl = cv ? c : k - 1;
-            const double x = p[cols ? cols[cl] : cl] - sub;
-            v[ps][i] = (rv && cv) ? x : 0.0;
+            ci[i] = cols[((i < C::NT - 1) || (c < k)) ? c : k - 1];
         }
+    } else {
+#pragma unroll
+        for (int i = 0; i < C::NT; ++i) {
+            const int c = cb + 16 * i;
+            ci[i] = ((i < C::NT - 1) || (c < k)) ? c : k - 1;   // k >= 16 (NT-1): only the last group needs the clamp
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < C::PASSES; ++ps) {
+        const int r = chunk * C::CH + ps * C::ROWS_PER_PASS + (tid >> 4);
+        const int rc = (r < src.count) ? r : src.count - 1;   // clamp (count >= 1 is validated on the host)
+        const long long row = src.ridx ? (long long)src.ridx[rc] : src.first + rc;
+        sub[ps] = 0.0;
+        if (!HF && src.sub_row) sub[ps] = src.sub_row[rc];
+        const double* p = src.base + row * (long long)src.ld;
+#pragma unroll
+        for (int i = 0; i < C::NT; ++i) v[ps][i] = p[ci[i]];
     }
 }
 
@@ -230,7 +244,8 @@ __device__ __forceinline__ void load_chunk(const RowSource& src, const int* __re
 // them to the LDS staging buffer.
 template <class C, bool HF>
 __device__ __forceinline__ void store_chunk(double* __restrict__ buf, const double* __restrict__ lds, int k,
-                                            int chunk, int count, int tid, double (&v)[C::PASSES][C::NT]) {
+                                            int chunk, int count, int tid, double (&v)[C::PASSES][C::NT],
+                                            const double (&sub)[C::PASSES]) {
     const int cb = tid & 15;
     constexpr int kI = C::NT - 1;            // the border column k always lies in the last 16-column group
     const int kc = k - 16 * kI;
@@ -250,6 +265,12 @@ __device__ __forceinline__ void store_chunk(double* __restrict__ buf, const doub
             z = rowgroup_sum16(z);
             if (cb == kc) v[ps][kI] = z;                 // border column: z_r = (y_r - ybar).w0
         } else {
+#pragma unroll
+            for (int i = 0; i < C::NT; ++i) {
+                const int c = cb + 16 * i;
+                const bool cv = (i < kI) || (c < k);
+                v[ps][i] = (rv && cv) ? v[ps][i] - sub[ps] : 0.0;          // ref:57
+            }
             if (cb == kc) v[ps][kI] = rv ? 1.0 : 0.0;    // border column: ones -> t = X'1
         }
 #pragma unroll
@@ -278,13 +299,25 @@ __device__ __forceinline__ void mfma_tiles(const double* __restrict__ lanebase, 
 
 template <class C, bool HF, int FIX>
 __device__ __forceinline__ void gram_phase(const RowSource& src, const int* __restrict__ cols, int k, double* lds,
-                                           int tid0, int wv, d4 (&acc)[C::SLOTS]) {
+                                           int tid0, int wv, d4 (&acc)[C::SLOTS], long long* loopstamps) {
+#ifdef TP_STAMP
+    // diagnostic: time spent in the four segments of a chunk iteration (issue loads | MFMA block |
+    // finish + LDS write | barrier), summed over the phase, for the wave this body is specialised for
+    long long seg[4] = {0, 0, 0, 0};
+    long long tprev = 0;
+#define TP_LOOPSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const long long tn = (long long)__builtin_amdgcn_s_memtime(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); \
+        if ((i) > 0) seg[((i) > 0) ? (i) - 1 : 0] += tn - tprev; tprev = tn; } while (0)
+#else
+#define TP_LOOPSTAMP(i) do { } while (0)
+#endif
     const int nchunks = (src.count + C::CH - 1) / C::CH;
     double v[C::PASSES][C::NT];
+    double sub[C::PASSES];
     if (nchunks > 0) {
         const int tid = fresh(tid0);
-        load_chunk<C, HF>(src, cols, k, 0, tid, v);
-        store_chunk<C, HF>(lds + C::OFF_STAGE0, lds, k, 0, src.count, tid, v);
+        load_chunk<C, HF>(src, cols, k, 0, tid, v, sub);
+        store_chunk<C, HF>(lds + C::OFF_STAGE0, lds, k, 0, src.count, tid, v, sub);
     }
     __syncthreads();
 #pragma nounroll
@@ -294,15 +327,27 @@ __device__ __forceinline__ void gram_phase(const RowSource& src, const int* __re
         double* cur = lds + ((ch & 1) ? C::OFF_STAGE1 : C::OFF_STAGE0);
         double* nxt = lds + ((ch & 1) ? C::OFF_STAGE0 : C::OFF_STAGE1);
         const bool more = ch + 1 < nchunks;
-        if (more) load_chunk<C, HF>(src, cols, k, ch + 1, tid, v);       // global loads in flight under the MFMAs
+        TP_LOOPSTAMP(0);
+        if (more) load_chunk<C, HF>(src, cols, k, ch + 1, tid, v, sub);       // global loads in flight under the MFMAs
         __builtin_amdgcn_sched_barrier(0);   // the scheduler must not sink these loads below the MFMA block
+        TP_LOOPSTAMP(1);
         const double* lanebase = cur + fq * C::LDX + fr;
         wave_sel<C::NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
             mfma_tiles<C, decltype(wc)::value, C::CH, false>(lanebase, acc, [](int, int) { return true; });
         });
-        if (more) store_chunk<C, HF>(nxt, lds, k, ch + 1, src.count, tid, v);
+        TP_LOOPSTAMP(2);
+        if (more) store_chunk<C, HF>(nxt, lds, k, ch + 1, src.count, tid, v, sub);
+        TP_LOOPSTAMP(3);
         __syncthreads();
+        TP_LOOPSTAMP(4);
     }
+#ifdef TP_STAMP
+    if (loopstamps && (tid0 & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) loopstamps[4 * wv + i] = seg[i];
+    }
+#endif
+#undef TP_LOOPSTAMP
 }
 
 template <int NT, int NW, int FIX>
@@ -324,9 +369,6 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
 
     const int* cols = A.col_idx ? A.col_idx + w * k : nullptr;
     d4 acc[C::SLOTS];
-    static_for<0, C::SLOTS>([&](auto sc_) __attribute__((always_inline)) {
-        acc[decltype(sc_)::value] = d4{0.0, 0.0, 0.0, 0.0};
-    });
 
     double n0 = 0.0, cc = 0.0, q0 = 0.0;
     const bool conj = A.strategy == 0;
@@ -374,6 +416,18 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
             for (int i = 0; i < C::NT; ++i) cs[i] = 0.0;
             const int cb = tid & 15;
             const int iters = (hs.count + C::ROWS_PER_PASS - 1) / C::ROWS_PER_PASS;
+            int ci[C::NT];
+            bool cv[C::NT];
+#pragma unroll
+            for (int i = 0; i < C::NT; ++i) {
+                const int c = cb + 16 * i;
+                cv[i] = (i < C::NT - 1) || (c < k);
+                ci[i] = cv[i] ? c : k - 1;                                  // clamp: load unconditionally
+            }
+            if (cols) {
+#pragma unroll
+                for (int i = 0; i < C::NT; ++i) ci[i] = cols[ci[i]];
+            }
 #pragma unroll 4
             for (int it = 0; it < iters; ++it) {                            // loads of 4 iterations in flight
                 const int r = it * C::ROWS_PER_PASS + (tid >> 4);
@@ -383,11 +437,8 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
                 const double* p = hs.base + row * (long long)hs.ld;
 #pragma unroll
                 for (int i = 0; i < C::NT; ++i) {
-                    const int c = cb + 16 * i;
-                    const bool cv = (i < C::NT - 1) || (c < k);
-                    const int cl = cv ? c : k - 1;                          // clamp: load unconditionally
-                    const double x = p[cols ? cols[cl] : cl];
-                    cs[i] += (rv && cv) ? x : 0.0;
+                    const double x = p[ci[i]];
+                    cs[i] += (rv && cv[i]) ? x : 0.0;
                 }
             }
             double* part = lds + C::OFF_STAGE0;                             // [ROWS_PER_PASS][LDX]
@@ -404,8 +455,12 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
             __syncthreads();
         }
         TP_MARK(1);
+        // the accumulators come to life only now: phase A had the whole register file for its loads
+        static_for<0, C::SLOTS>([&](auto sc_) __attribute__((always_inline)) {
+            acc[decltype(sc_)::value] = d4{0.0, 0.0, 0.0, 0.0};
+        });
         // ---- phase B: centred intraday Gram
-        gram_phase<C, true, FIX>(hs, cols, k, lds, tid0, wv, acc);
+        gram_phase<C, true, FIX>(hs, cols, k, lds, tid0, wv, acc, nullptr);
         TP_MARK(2);
         // ---- phase C: q0, c, scaling (ref:333, 415-418)
         {
@@ -447,6 +502,11 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
         if (dbg == 1) { dump_matrix(); return; }
     }
 
+    if (!(conj && dbg != 2)) {
+        static_for<0, C::SLOTS>([&](auto sc_) __attribute__((always_inline)) {
+            acc[decltype(sc_)::value] = d4{0.0, 0.0, 0.0, 0.0};
+        });
+    }
     TP_MARK(3);
     // ---- phase D: daily Gram (ref:180) + t in the border column (ref:222)
     {
@@ -456,7 +516,7 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
         ds.first = A.start ? A.start[w] : 0;
         ds.sub_row = A.rf_adj ? A.rf_adj + w * (long long)A.n_r : nullptr;
         ds.count = A.n_rows ? A.n_rows[w] : A.n_r;
-        gram_phase<C, false, FIX>(ds, cols, k, lds, tid0, wv, acc);
+        gram_phase<C, false, FIX>(ds, cols, k, lds, tid0, wv, acc, TP_LOOPSTAMP_PTR);
     }
 
     {

@@ -18,6 +18,8 @@ for _ in range(3):
 dev.synchronize()
 st = b.debug_stamps()
 print("kernel_ms", dev.last_timing()["kernel_ms"], dev.last_launch())
+loop = st[:, 8:24].reshape(-1, 4, 4).astype(np.float64)
+st = st[:, :8]
 d = np.diff(st, axis=1).astype(np.float64)
 names = ["A means", "B hf gram", "C scale", "D daily gram", "F cholesky", "G backsolve", "H output"]
 tot = (st[:, 7] - st[:, 0]).astype(np.float64)
@@ -26,3 +28,8 @@ for i, n in enumerate(names):
     print(f"  {n:14s} median {np.median(d[:, i]):8.0f} ticks  share {np.median(d[:, i]) / np.median(tot) * 100:5.1f}%")
 span = st[:, 7].max() - st[:, 0].min()
 print("launch span ticks", span, "=> ms", span / 1e5)
+
+print("daily Gram loop, summed cycles per window by segment (median over windows), per wave:")
+for wv in range(4):
+    m = np.median(loop[:, wv, :], axis=0)
+    print(f"  wave {wv}: issue-loads {m[0]:8.0f}  mfma {m[1]:8.0f}  finish+lds-write {m[2]:8.0f}  barrier {m[3]:8.0f}  total {m.sum():8.0f}")
