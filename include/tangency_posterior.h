@@ -124,9 +124,10 @@ int tp_batch_download_S1(tp_batch_t b, int64_t w, double* S1 /* [k x k] */); /* 
 #define TP_MATRIX_POSTERIOR 3  /* S1 (ref:358) / J (ref:600)  and c S0 w0 + t (ref:489) / t   */
 int tp_batch_download_matrix(tp_batch_t b, int64_t w, int what, double* M /* [k x k] */, double* rhs /* [k] */);
 /* Diagnostic builds only (make TP_STAMP=1; otherwise TP_ERR_UNSUPPORTED): run the batch once and return
- * 24 values per window: eight shader-clock stamps at the kernel's phase boundaries, then per wave (4)
- * the summed cycles of the four segments of the daily Gram loop (loads | MFMA | LDS write | barrier). */
-int tp_batch_debug_stamps(tp_batch_t b, int64_t* stamps /* [W x 24] */);
+ * 40 values per window: eight shader-clock stamps at the kernel's phase boundaries, then per wave (4)
+ * the summed cycles of the four segments of the daily Gram loop (loads | MFMA | LDS write | barrier),
+ * then for waves 0 and 1 those of a factorisation block step (hand-over | elimination | TRSM | trailing). */
+int tp_batch_debug_stamps(tp_batch_t b, int64_t* stamps /* [W x 40] */);
 int tp_batch_destroy(tp_batch_t b);
 
 /* One-shot convenience: upload + run + download.  Replaces

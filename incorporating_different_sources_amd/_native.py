@@ -282,7 +282,7 @@ class Batch:
 
     def debug_stamps(self) -> np.ndarray:
         """[W x 8] shader-clock stamps at the kernel's phase boundaries (TP_STAMP builds only)."""
-        st = np.zeros((self.W, 24), dtype=np.int64)
+        st = np.zeros((self.W, 40), dtype=np.int64)
         self.dev._check(lib.tp_batch_debug_stamps(self._b, _ptr(st, c_int64)))
         return st
 

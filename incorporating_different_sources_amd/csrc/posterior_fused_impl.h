@@ -47,8 +47,8 @@ constexpr int tp_kstep_unroll = TP_KSTEP_UNROLL;
 // Diagnostic build only (make TP_STAMP=1): per-window s_memtime stamps at the phase boundaries, written
 // to a buffer of their own (never into an output).  The product build compiles none of this.
 #ifdef TP_STAMP
-#define TP_LOOPSTAMP_PTR (A.stamps ? A.stamps + (w - A.w_first) * 24 + 8 : nullptr)
-#define TP_MARK(slot) do { if (A.stamps && (tid0 == 0)) A.stamps[(w - A.w_first) * 24 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define TP_LOOPSTAMP_PTR (A.stamps ? A.stamps + (w - A.w_first) * 40 + 8 : nullptr)
+#define TP_MARK(slot) do { if (A.stamps && (tid0 == 0)) A.stamps[(w - A.w_first) * 40 + (slot)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define TP_LOOPSTAMP_PTR nullptr
 #define TP_MARK(slot) do { } while (0)
@@ -118,6 +118,16 @@ __device__ __forceinline__ double rowgroup_sum16(double v) {
 __device__ __forceinline__ int fresh(int x) {
     asm volatile("" : "+v"(x));
     return x;
+}
+
+// 1/d: v_rcp_f64 seed + two Newton steps (5 dependent DP operations)
+__device__ __forceinline__ double rcp_nr(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    return y;
 }
 
 // 1/sqrt(d): v_rsq_f64 seed (about 2^-24 relative) + two Newton steps; a non-positive or NaN d
@@ -568,9 +578,19 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
     // j turns into y_j = (R^-T b)_j on the way: the forward substitution costs nothing extra.
     double* RB = lds + C::OFF_STAGE0;          // block row j of R, [16][LDX]
     double* MB = lds + C::OFF_STAGE1;          // M_j transposed, [NTB][16][16]: MB[j][c][i] = M_j[i][c]
+#ifdef TP_STAMP
+    long long fseg[4] = {0, 0, 0, 0};
+    long long ft = 0;
+#define TP_FSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const long long tn = (long long)__builtin_amdgcn_s_memtime(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); \
+        if ((i) > 0) fseg[((i) > 0) ? (i) - 1 : 0] += tn - ft; ft = tn; } while (0)
+#else
+#define TP_FSTAMP(i) do { } while (0)
+#endif
 #pragma nounroll
     for (int j = 0; j < NTB; ++j) {
         TP_LANE_CONSTANTS();
+        TP_FSTAMP(0);
         const int npiv = (k - 16 * j < 16) ? (k - 16 * j) : 16;
         double* DG = lds + C::OFF_DIAG + (j & 1) * 256;
         // (1) diagonal tile -> LDS, row-major
@@ -584,11 +604,15 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
             });
         });
         __syncthreads();
+        TP_FSTAMP(1);
         // (2) elimination by one wave: lane c < 16 holds column c of the tile, lane 16 + c column c
         //     of the identity.  Pivots past npiv (last block row only) are made inert by selects, so
         //     the 16 steps are one straight-line block.
         // Only wave 0's instantiation carries this code (the window body is specialised per wave).
         if ((FIX == 0 || FIX < 0) && wv == 0) {
+            // the pivot chain is the critical path of the window while three waves of this workgroup
+            // wait at the barrier: let it win the SIMD's issue arbitration against other workgroups
+            __builtin_amdgcn_s_setprio(3);
             const int c16 = lane & 15;
             double a[16];
 #pragma unroll
@@ -597,32 +621,49 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
                 a[i] = (lane < 16) ? x : ((lane < 32 && c16 == i) ? 1.0 : 0.0);
             }
             bool bad = false;
+            // The pivot loop is ISSUE-bound, not latency-bound: one wavefront issues an fp64 VALU
+            // operation every ~8 cycles and each multiplier costs 2 v_readlane + 1 FMA, so what counts
+            // is the instruction count (measured: a square-root-free variant with a shorter dependent
+            // chain but one more multiply per multiplier was 8 % slower).  Look-ahead: as soon as pivot
+            // p has updated row p+1 the next pivot's rsqrt (v_rsq_f64 + 2 Newton steps) is started, so
+            // it overlaps the remaining row updates of pivot p.
+            double d0 = readlane_d(a[0], 0);
+            bad |= !(d0 > 0.0);
+            double rinv = rsqrt_nr(d0);
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
-                const bool live = p < npiv;
-                double d = readlane_d(a[p], p);
-                bad |= live && !(d > 0.0);
-                d = live ? d : 1.0;
-                const double rinv = rsqrt_nr(d);
-                a[p] *= rinv;
+                if (p < npiv) {                 // wave-uniform: the last block row stops at its last real pivot
+                    a[p] *= rinv;
+                    double rinv_next = 1.0;
+                    if (p + 1 < 16) {
+                        const double s1 = readlane_d(a[p], p + 1);
+                        a[p + 1] = fma(-s1, a[p], a[p + 1]);
+                        double dn = readlane_d(a[p + 1], p + 1);
+                        const bool live = p + 1 < npiv;
+                        bad |= live && !(dn > 0.0);
+                        dn = live ? dn : 1.0;
+                        rinv_next = rsqrt_nr(dn);
+                    }
 #pragma unroll
-                for (int i = p + 1; i < 16; ++i) {
-                    // (past npiv the multipliers are zero by construction: row kc only holds
-                    //  products with the zero columns beyond the border, rows after it are zero)
-                    const double sI = readlane_d(a[p], i);
-                    a[i] = fma(-sI, a[p], a[i]);
+                    for (int i = p + 2; i < 16; ++i) {
+                        const double sI = readlane_d(a[p], i);
+                        a[i] = fma(-sI, a[p], a[i]);
+                    }
+                    rinv = rinv_next;
+                    // keep the scheduler from hoisting later pivots' v_readlane results (SGPR pairs)
+                    // across this point: one pivot's pairs fit the scalar file, all 136 do not
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                // keep the scheduler from hoisting the next pivots' v_readlane results (SGPR pairs)
-                // across this point: one pivot's 16 pairs fit the scalar file, all 136 do not
-                __builtin_amdgcn_sched_barrier(0);
             }
             if (lane >= 16 && lane < 32) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) MB[j * 256 + c16 * 16 + i] = a[i];
             }
             if (bad && lane == 0) lds[C::OFF_SCAL + 1] = 1.0;
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
+        TP_FSTAMP(2);
         // (3) block row j: R_jJ = M A_jJ  (A operand M from LDS, B operand = the tile's own registers)
         wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
             for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
@@ -643,6 +684,7 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
             });
         });
         __syncthreads();
+        TP_FSTAMP(3);
         // (4) trailing update A_IJ -= R_jI' R_jJ (I > j) by MFMA from the LDS image of block row j
         {
             const double* lanebase = RB + fq * C::LDX + fr;
@@ -651,7 +693,15 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
             });
         }
         // no barrier here: RB is rewritten two barriers later, DG alternates between two buffers
+        TP_FSTAMP(4);
     }
+#ifdef TP_STAMP
+    if (A.stamps && (tid0 & 63) == 0 && wv < 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) A.stamps[(w - A.w_first) * 40 + 24 + 4 * wv + i] = fseg[i];
+    }
+#endif
+#undef TP_FSTAMP
 
     TP_MARK(5);
     // ---- phase G: y, q1, back substitution R w = y with the R tiles still in registers

@@ -472,12 +472,12 @@ int tp_batch_debug_stamps(tp_batch_t b, int64_t* stamps) {
     tp_handle_t h = b->h;
 #ifdef TP_STAMP
     HIP_TRY(h, hipSetDevice(h->device));
-    int rc = ensure(h, b->stamps, sizeof(int64_t) * (size_t)b->W * 24);
+    int rc = ensure(h, b->stamps, sizeof(int64_t) * (size_t)b->W * 40);
     if (rc != TP_OK) return rc;
-    HIP_TRY(h, hipMemsetAsync(b->stamps.p, 0, sizeof(int64_t) * (size_t)b->W * 24, h->stream));
+    HIP_TRY(h, hipMemsetAsync(b->stamps.p, 0, sizeof(int64_t) * (size_t)b->W * 40, h->stream));
     rc = tp_batch_run(b);
     if (rc != TP_OK) return rc;
-    HIP_TRY(h, hipMemcpyAsync(stamps, b->stamps.p, sizeof(int64_t) * (size_t)b->W * 24, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(stamps, b->stamps.p, sizeof(int64_t) * (size_t)b->W * 40, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return harvest_kernel_time(h);
 #else

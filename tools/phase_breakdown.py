@@ -19,6 +19,7 @@ dev.synchronize()
 st = b.debug_stamps()
 print("kernel_ms", dev.last_timing()["kernel_ms"], dev.last_launch())
 loop = st[:, 8:24].reshape(-1, 4, 4).astype(np.float64)
+fseg = st[:, 24:32].reshape(-1, 2, 4).astype(np.float64)
 st = st[:, :8]
 d = np.diff(st, axis=1).astype(np.float64)
 names = ["A means", "B hf gram", "C scale", "D daily gram", "F cholesky", "G backsolve", "H output"]
@@ -33,3 +34,8 @@ print("daily Gram loop, summed cycles per window by segment (median over windows
 for wv in range(4):
     m = np.median(loop[:, wv, :], axis=0)
     print(f"  wave {wv}: issue-loads {m[0]:8.0f}  mfma {m[1]:8.0f}  finish+lds-write {m[2]:8.0f}  barrier {m[3]:8.0f}  total {m.sum():8.0f}")
+
+print("factorisation, summed cycles per window by block-step segment (median), waves 0 and 1:")
+for wv in range(2):
+    m = np.median(fseg[:, wv, :], axis=0)
+    print(f"  wave {wv}: hand-over+barrier {m[0]:8.0f}  elimination+barrier {m[1]:8.0f}  trsm+barrier {m[2]:8.0f}  trailing {m[3]:8.0f}  total {m.sum():8.0f}")
