@@ -93,7 +93,7 @@ def main():
     def step():
         batch.run()
         if gather_mode == "rccl":
-            batch.gather(root=0)
+            batch.gather(root=0, to_host=False)      # gathered weights stay in rank 0's HBM, like N=1
         elif gather_mode == "host-gloo":
             wts, st, _ = batch.download(want_aux=False)
             cp.gather_host(wts, root=0)
@@ -117,6 +117,11 @@ def main():
 
     weights, status, aux = batch.download()
     d2h_ms = dev.last_timing()["d2h_ms"]
+    gathered_ok = None
+    if gather_mode == "rccl" and cp.rank == 0:
+        wall, sall = batch.download_gathered()                   # after the timed region: check the collective
+        gathered_ok = bool(np.array_equal(wall[0], weights) and np.array_equal(sall[0], status)
+                           and np.isfinite(wall).all())
     n_bad = int((status != 0).sum())
     launch = dev.last_launch()
     info = dev.info()
@@ -186,7 +191,7 @@ def main():
                                    + (f" (m={m} intraday returns, VIX-style n0)" if conj else ""),
                        "k": k, "N": N, "n_r": n_r, "m": m if conj else 0, "windows_per_gpu": W,
                        "strategy": args.strategy, "parallelism": f"windows sharded x{cp.world}",
-                       "gather": gather_mode, "seed": shp["seed"]},
+                       "gather": gather_mode, "gather_verified": gathered_ok, "seed": shp["seed"]},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes)" if traffic else None,

@@ -154,9 +154,11 @@ int tp_last_launch(tp_handle_t h, int* grid, int* block, int* lds_bytes, int* nt
 int tp_comm_unique_id(void* id /* [TP_UNIQUE_ID_BYTES] */);
 int tp_comm_init(tp_handle_t h, const void* id, int rank, int world);
 int tp_comm_destroy(tp_handle_t h);
-/* Every rank calls it with the same W_local; on root, weights_all [world x W x k] and
- * status_all [world x W] are HOST buffers filled after the gather (NULL elsewhere). */
+/* Every rank calls it with the same W_local.  The gathered [world x W x k] weights and [world x W]
+ * statuses stay in root's HBM; weights_all / status_all are optional HOST buffers on root (NULL: no
+ * copy-out, fetch later with tp_batch_download_gathered). */
 int tp_batch_gather(tp_batch_t b, int root, double* weights_all, int32_t* status_all);
+int tp_batch_download_gathered(tp_batch_t b, double* weights_all, int32_t* status_all); /* root only */
 
 #ifdef __cplusplus
 }

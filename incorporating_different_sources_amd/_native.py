@@ -33,7 +33,7 @@ EXPORTS = [
     "tp_batch_create", "tp_batch_upload", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1", "tp_batch_download_matrix", "tp_batch_debug_stamps",
     "tp_batch_destroy", "tp_posterior_batch", "tp_synchronize", "tp_last_timing", "tp_region_begin",
     "tp_region_end", "tp_last_launch", "tp_comm_unique_id", "tp_comm_init", "tp_comm_destroy",
-    "tp_batch_gather",
+    "tp_batch_gather", "tp_batch_download_gathered",
 ]
 
 
@@ -89,6 +89,7 @@ def _load():
     lib.tp_comm_init.argtypes = [c_void_p, c_void_p, c_int, c_int]
     lib.tp_comm_destroy.argtypes = [c_void_p]
     lib.tp_batch_gather.argtypes = [c_void_p, c_int, POINTER(c_double), POINTER(c_int32)]
+    lib.tp_batch_download_gathered.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int32)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is not c_char_p:
@@ -286,16 +287,25 @@ class Batch:
         self.dev._check(lib.tp_batch_debug_stamps(self._b, _ptr(st, c_int64)))
         return st
 
-    def gather(self, root=0):
-        """One RCCL gather of every rank's [W x k] weights (and statuses) to `root`."""
+    def gather(self, root=0, to_host=True):
+        """One RCCL gather of every rank's [W x k] weights (and statuses) to `root`.  With
+        `to_host=False` the result stays in root's HBM (`download_gathered` fetches it later)."""
         world, rank = self.dev.world, self.dev.rank
-        if rank == root:
+        self._gather_root = root
+        if rank == root and to_host:
             wall = np.empty((world, self.W, self.k), dtype=np.float64)
             sall = np.empty((world, self.W), dtype=np.int32)
             self.dev._check(lib.tp_batch_gather(self._b, root, _ptr(wall, c_double), _ptr(sall, c_int32)))
             return wall, sall
         self.dev._check(lib.tp_batch_gather(self._b, root, None, None))
         return None, None
+
+    def download_gathered(self):
+        world = self.dev.world
+        wall = np.empty((world, self.W, self.k), dtype=np.float64)
+        sall = np.empty((world, self.W), dtype=np.int32)
+        self.dev._check(lib.tp_batch_download_gathered(self._b, _ptr(wall, c_double), _ptr(sall, c_int32)))
+        return wall, sall
 
 
 _default_device = None

@@ -1,33 +1,49 @@
 #pragma once
-// posterior_fused.hip - fused per-window posterior kernel for gfx950 (MI355X), register-tile path.
+// posterior_fused_impl.h - fused per-window posterior kernel for gfx950 (MI355X), register-tile path
+// (k <= 239).  Instantiated once per tile count by posterior_fused_nt.hip.
 //
-// One workgroup (NW wavefronts of 64 lanes) owns one rolling window at a time and keeps the whole
-// upper triangle of the (k+1) x (k+1) bordered posterior matrix
+// One workgroup (NW wavefronts of 64 lanes) owns one rolling window and keeps the whole upper triangle
+// of the (k+1) x (k+1) bordered posterior matrix
 //
 //        [ S1   b ]      S1 = n0 m/(m-1) (Y-Ybar)'(Y-Ybar) + X'X        (ref:317-333, 180, 358)
 //        [ b'   * ]      b  = c S0 w0 + t                               (ref:489 right-hand side)
 //
 // in v_mfma_f64_16x16x4_f64 accumulator tiles (16x16, NT tiles per side, tile (I,J), I<=J, lives in
-// ONE wave's registers for the whole window).  ref:LINE cites /root/reference/src/portfolio_calculations.py.
+// ONE wave's registers from the first Gram MFMA to the last back-substitution product).
+// ref:LINE cites /root/reference/src/portfolio_calculations.py.
 //
-//   phase A  column means of the intraday rows (two-pass centring like DataFrame.cov, ref:317)
-//   phase B  Gram of the centred intraday rows, staged 16 rows at a time through LDS; column k of the
-//            staged rows carries z_r = (y_r - ybar).w0, so the MFMA also yields C w0 and w0'C w0
+//   phase A  column means of the intraday rows (two-pass centring like DataFrame.cov, ref:317):
+//            16-lane coalesced row segments, four iterations of loads in flight
+//   phase B  Gram of the centred intraday rows, staged 16 rows at a time global -> registers -> LDS
+//            (double-buffered; the next chunk's RAW loads are issued before the MFMA block and consumed
+//            after it); column k of the staged rows carries z_r = (y_r - ybar).w0, so the same MFMAs
+//            yield C w0 (border column) and w0'C w0
 //   phase C  q0, c (ref:415-418); scale tiles by s = n0 m/(m-1), the border column by c s
 //   phase D  Gram of the daily excess returns on top (ref:180); column k of the staged rows is 1, so
 //            the border column accumulates t = X'1 (ref:222)
 //   phase E  (Jeffreys) J = T - t t'/N (ref:600-601)
-//   phase F  blocked upper Cholesky S1 = R'R over 16-row block rows: a block row goes through LDS,
-//            every wave applies the 16 pivots' row operations to <=48 of its columns (one column per
-//            lane, pivot multipliers by v_readlane from the redundantly held diagonal tile), and the
-//            trailing tiles are updated by MFMA from the same LDS image.  The border column comes out
-//            as y = R^-T b (forward substitution for free); R_jj^-T falls out of 16 identity columns.
+//   phase F  blocked upper Cholesky S1 = R'R, 16-row block steps: the diagonal tile goes to wave 0
+//            through LDS; wave 0 eliminates it (column per lane, 16 pivots, multipliers by v_readlane,
+//            rsqrt with look-ahead) together with 16 identity columns => M = R_jj^-T; every tile of the
+//            block row becomes R_jJ = M A_jJ by MFMA with the tile's OWN accumulator registers as the B
+//            operand; the trailing tiles are updated by MFMA from the LDS image of the block row.  The
+//            border column comes out as y = R^-T b: the forward substitution is free.
 //   phase G  q1 = y'y (= w1'S1 w1, ref:574), blocked back substitution R w1 = y with the R tiles
-//            still in registers
+//            still in registers (DPP row reductions, partial sums added in fixed order)
 //   phase H  weights = (n1+k+2) w1 / (n1-q1) / gamma (ref:572-575, 836) or w/gamma (ref:849)
 //
 // HBM traffic per window is the algorithmic minimum: each panel row of the window is read once
-// (plus once more for the intraday means, from L2), k weights are written.
+// (plus once more for the intraday means, mostly from L2 / Infinity Cache), k weights are written.
+//
+// Notes for whoever edits this file (each cost a measurable factor on MI355X):
+//  * tile coordinates must be compile-time constants (for_tiles / static_for) and the whole window
+//    body is instantiated per wave index (TP_WAVE_SPECIALISE): otherwise the accumulator array is
+//    indexed through pointer-phis and lands in scratch;
+//  * build with -mllvm -sink-common-insts=false for the same reason;
+//  * nothing may consume a prefetched panel value before the MFMA block (load_chunk), and the
+//    col_idx select must sit OUTSIDE the load loop: either mistake serialises the loads;
+//  * lane constants are re-derived per phase from a laundered thread id (fresh()): CSE across phases
+//    otherwise keeps ~100 registers alive for the whole kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -69,7 +85,6 @@ struct Cfg {
     static constexpr int CH = (NW == 8) ? 32 : 16;       // staged rows per chunk
     static constexpr int ROWS_PER_PASS = NTHREADS / 16;  // 16 threads per staged row
     static constexpr int PASSES = CH / ROWS_PER_PASS;
-    static constexpr int COLCAP = 48 * NW;               // non-diagonal columns the waves can eliminate at once
     static_assert(PASSES >= 1, "bad staging geometry");
     // LDS carve (doubles)
     static constexpr int STAGE = CH * LDX;               // one staging buffer; buffer 0 doubles as the block-row
@@ -155,8 +170,6 @@ template <int NT>
 constexpr int tile_I(int t) { int i = 0, rem = t; while (rem >= NT - i) { rem -= NT - i; ++i; } return i; }
 template <int NT>
 constexpr int tile_J(int t) { int i = 0, rem = t; while (rem >= NT - i) { rem -= NT - i; ++i; } return i + rem; }
-template <int NT>
-constexpr int tile_index(int I, int J) { int t = 0; for (int i = 0; i < I; ++i) t += NT - i; return t + (J - I); }
 
 template <int V> using ic = std::integral_constant<int, V>;
 

@@ -50,6 +50,7 @@ struct tp_batch_s {
     DevBuf t_arena, t_rinv, t_ybar, t_zc, t_scal, t_flags;   // large-k path workspace
     int64_t tiled_capacity = 0;                               // windows in flight per sub-batch
     bool uploaded = false;
+    bool gathered = false;
 };
 
 namespace {
@@ -592,11 +593,20 @@ int tp_batch_gather(tp_batch_t b, int root, double* weights_all, int32_t* status
     (void)hipEventDestroy(g1);
     int rc = harvest_kernel_time(h);
     if (rc != TP_OK) return rc;
-    if (is_root) {
-        if (weights_all) HIP_TRY(h, hipMemcpyAsync(weights_all, b->gather_w.p, sizeof(double) * nw * h->world, hipMemcpyDeviceToHost, h->stream));
-        if (status_all) HIP_TRY(h, hipMemcpyAsync(status_all, b->gather_s.p, sizeof(int32_t) * ns * h->world, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-    }
+    b->gathered = true;
+    if (is_root && (weights_all || status_all)) return tp_batch_download_gathered(b, weights_all, status_all);
+    return TP_OK;
+}
+
+int tp_batch_download_gathered(tp_batch_t b, double* weights_all, int32_t* status_all) {
+    if (!b) return TP_ERR_INVALID;
+    tp_handle_t h = b->h;
+    if (!b->gathered || !b->gather_w.p) return fail(h, TP_ERR_INVALID, "nothing gathered on this rank (root only, after tp_batch_gather)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nw = (size_t)b->W * b->p.k, ns = (size_t)b->W;
+    if (weights_all) HIP_TRY(h, hipMemcpyAsync(weights_all, b->gather_w.p, sizeof(double) * nw * h->world, hipMemcpyDeviceToHost, h->stream));
+    if (status_all) HIP_TRY(h, hipMemcpyAsync(status_all, b->gather_s.p, sizeof(int32_t) * ns * h->world, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     return TP_OK;
 }
 
