@@ -1,0 +1,307 @@
+"""Batch-native host packing: all rebalancing dates of a backtest are turned into
+ONE device batch in the panel + row-index + column-index layout of `include/tangency_posterior.h`,
+without touching pandas per date.
+
+The reference re-slices DataFrames for every date (`/root/reference/src/portfolio_calculations.py`
+ref:611-658 universe selection with a Python loop over tickers, ref:136-161 window + resample, ref:31-62
+log-returns twice per window, ref:299-314 intraday filter, ref:90-114 MCM window).  Here every frame is
+converted once per `market_data` into numpy panels (`MarketPanels`); a date then costs a few
+`searchsorted` calls and small index arithmetic, and the O(n k) values never leave the shared panels:
+
+* daily panel      `L[i] = log(P[i] / P[i-1])` (or the resampled weekly / monthly equivalent plus one
+                   "tail" row per date for the running bin, ref:149-156)
+* intraday panel   `H[i] = log(p[i] / p[i-1])` over consecutive bars
+* per window       row indices into the panels, the k column indices in market-cap order, the per-row
+                   risk-free adjustment (ref:40-57), prior weights w0 and strength n0
+
+`tests/test_host_batch_packing.py` holds this packer to the frame-based one
+(`portfolio_calculations._pack_window`, a line-by-line mirror of the reference's slicing) on every date.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+import pandas as pd
+
+logger = logging.getLogger(__name__)
+
+_NS_PER_DAY = 86_400_000_000_000
+_RESAMPLE_RULE = {"weekly": "W", "monthly": "ME"}
+_CALENDAR_DAYS = {"daily": 1, "weekly": 7, "monthly": 31}
+_TRADING_DAYS = {"daily": 1, "weekly": 5, "monthly": 22}
+
+
+def _ns(index) -> np.ndarray:
+    return pd.DatetimeIndex(index).values.astype("datetime64[ns]").astype(np.int64)
+
+
+def _resample_last(df, frequency):
+    try:
+        return df.resample(_RESAMPLE_RULE[frequency]).last()
+    except ValueError:  # pandas < 2.2
+        return df.resample("M" if frequency == "monthly" else "W").last()
+
+
+class MarketPanels:
+    """numpy views of `market_data`, built once per (market_data, rolling_window_frequency)."""
+
+    def __init__(self, market_data, frequency):
+        if frequency not in _CALENDAR_DAYS:
+            raise RuntimeError("Unknown rolling window frequency.")
+        self.frequency = frequency
+        prices = market_data["stock_prices_df"].sort_index()
+        self.tickers = list(prices.columns)
+        self.col_of = {t: i for i, t in enumerate(self.tickers)}
+        self.dates = prices.index
+        self.date_ns = _ns(prices.index)
+        self.P = prices.to_numpy(dtype=np.float64)
+        D, K = self.P.shape
+        # length of the run of non-NaN prices ending at each row (ref:646 `.tail(n).notna().all()`)
+        ok = ~np.isnan(self.P)
+        run = np.zeros((D, K), dtype=np.int32)
+        acc = np.zeros(K, dtype=np.int32)
+        for i in range(D):
+            acc = np.where(ok[i], acc + 1, 0)
+            run[i] = acc
+        self.valid_run = run
+
+        caps = market_data["stock_market_caps_df"]
+        self.caps_has = np.array([t in caps.columns for t in self.tickers])
+        self.caps_ns = _ns(caps.index)
+        self.caps = caps.reindex(columns=self.tickers).to_numpy(dtype=np.float64)
+
+        hf = market_data["stock_intraday_prices_df"].sort_index()
+        self.hf_has = np.array([t in hf.columns for t in self.tickers])
+        self.hf_ns = _ns(hf.index)
+        Hp = hf.reindex(columns=self.tickers).to_numpy(dtype=np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            H = np.full_like(Hp, np.nan)
+            if len(Hp) > 1:
+                H[1:] = np.log(Hp[1:] / Hp[:-1])              # H[i]: return from bar i-1 to bar i
+        self.H = np.ascontiguousarray(H)
+        self.hf_notna_cum = np.concatenate([np.zeros((1, K), np.int32), np.cumsum(~np.isnan(Hp), axis=0, dtype=np.int32)])
+
+        rf = market_data["risk_free_rate_df"]
+        self.rf_ns = _ns(rf.index)
+        self.rf = rf.to_numpy(dtype=np.float64).reshape(len(rf), -1)[:, 0]
+
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if frequency == "daily":
+                L = np.full_like(self.P, np.nan)
+                L[1:] = np.log(self.P[1:] / self.P[:-1])      # L[i]: return from date i-1 to date i
+                self.L = np.ascontiguousarray(L)
+                self.label_ns = self.date_ns
+            else:
+                R = _resample_last(prices, frequency)          # complete bins are the same for every date
+                self.R = R.to_numpy(dtype=np.float64)
+                self.label_ns = _ns(R.index)
+                L = np.full_like(self.R, np.nan)
+                L[1:] = np.log(self.R[1:] / self.R[:-1])
+                self.L = np.ascontiguousarray(L)
+                # bin of each trading date: first label >= date (labels are bin ends)
+                self.bin_of = np.searchsorted(self.label_ns, self.date_ns, side="left")
+        self._mcm = {}
+
+    # -- market-condition metric (ref:90-114, 247-267) --------------------------------------------
+    def mcm(self, market_data, key):
+        if key not in self._mcm:
+            frame = market_data[key].sort_index()
+            vals = frame.to_numpy(dtype=np.float64).reshape(len(frame), -1)[:, 0]
+            entry = dict(ns=_ns(frame.index), vals=vals)
+            if self.frequency != "daily":
+                R = _resample_last(frame, self.frequency)
+                entry["rvals"] = R.to_numpy(dtype=np.float64).reshape(len(R), -1)[:, 0]
+                entry["rlabel_ns"] = _ns(R.index)
+            self._mcm[key] = entry
+        return self._mcm[key]
+
+
+_PANEL_CACHE = {}
+
+
+def panels_for(market_data, frequency) -> MarketPanels:
+    key = (id(market_data["stock_prices_df"]), id(market_data["stock_intraday_prices_df"]),
+           id(market_data["stock_market_caps_df"]), id(market_data["risk_free_rate_df"]), frequency)
+    hit = _PANEL_CACHE.get(key)
+    if hit is None or hit[0] is not market_data["stock_prices_df"]:
+        if len(_PANEL_CACHE) > 8:
+            _PANEL_CACHE.clear()
+        hit = (market_data["stock_prices_df"], MarketPanels(market_data, frequency))
+        _PANEL_CACHE[key] = hit
+    return hit[1]
+
+
+def _mean_gap_and_check(label_ns):
+    gaps = np.diff(label_ns) // _NS_PER_DAY                    # `.dt.days` of the label differences (ref:40)
+    mean_gap = gaps.mean()
+    assert gaps.max() <= mean_gap + 4, "Unexpected large gap between return dates."
+    return mean_gap
+
+
+def select_universe(mp: MarketPanels, pos, size, window_days, rebal_frequency, members):
+    """Column indices (into mp.tickers) of the `size` largest caps among eligible stocks, cap-descending
+    (ref:611-658; the caller passes the REBALANCING frequency as in ref:960, Appendix B-Q7)."""
+    if rebal_frequency not in _CALENDAR_DAYS:
+        logger.error("Unknown rolling window frequency.")
+        raise RuntimeError("Unknown rolling window frequency.")
+    span = _CALENDAR_DAYS[rebal_frequency]
+    d = mp.date_ns[pos]
+    need = min(window_days, pos + 1)
+    elig = members & mp.caps_has & mp.hf_has & (mp.valid_run[pos] >= need)
+    a = np.searchsorted(mp.hf_ns, d - span * _NS_PER_DAY, side="left")     # label slice, both ends inclusive
+    b = np.searchsorted(mp.hf_ns, d + _NS_PER_DAY, side="right")
+    elig &= (mp.hf_notna_cum[b] - mp.hf_notna_cum[a]) > 0
+    ci = np.searchsorted(mp.caps_ns, d)
+    if ci >= len(mp.caps_ns) or mp.caps_ns[ci] != d:
+        ts = mp.dates[pos]
+        logger.error(f"The trading date {ts} does not exist in the market capitalizations data.")
+        raise ValueError(f"The trading date {ts} does not exist in the market capitalizations data.")
+    caps = mp.caps[ci]
+    cand = np.flatnonzero(elig & ~np.isnan(caps))
+    order = cand[np.argsort(-caps[cand], kind="stable")][:size]            # nlargest keeps the first of ties
+    return order.astype(np.int32), caps[order]
+
+
+def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None):
+    """All rebalancing dates of one spec -> keyword arguments of `_native.posterior_batch` plus the
+    per-window ticker labels.  Raises the reference's exceptions for the reference's conditions."""
+    strategy = portfolio_spec["weighting_strategy"]
+    freq = portfolio_spec["rolling_window_frequency"]
+    N, k = portfolio_spec["rolling_window"], portfolio_spec["size"]
+    conj = strategy.startswith("conjugate")
+    mp = panels_for(market_data, freq)
+    window_days = N * _TRADING_DAYS[freq]
+    W = len(trading_dates)
+    K = len(mp.tickers)
+    n_r_max = N - 1
+
+    col_idx = np.zeros((W, k), dtype=np.int32)
+    labels = []
+    row_idx = np.zeros((W, n_r_max), dtype=np.int32)
+    n_rows = np.zeros(W, dtype=np.int32)
+    rf_adj = np.zeros((W, n_r_max), dtype=np.float64)
+    tails = []                                           # extra panel rows (running-bin returns), resampled windows
+    w0 = np.zeros((W, k)) if conj else None
+    n0 = np.zeros(W) if conj else None
+    hf_rows, hf_count = [], np.zeros(W, dtype=np.int32)
+    base_rows = mp.L.shape[0]
+    mcm = mp.mcm(market_data, "vix_prices_df" if "_vix_" in strategy else "epu_prices_df") if conj else None
+    all_members = np.ones(K, dtype=bool)
+
+    for w, ts in enumerate(trading_dates):
+        d = pd.Timestamp(ts).value
+        pos = int(np.searchsorted(mp.date_ns, d))
+        if pos >= len(mp.date_ns) or mp.date_ns[pos] != d:
+            raise ValueError(f"trading_date_ts {ts} must be the last date in the DataFrame.")
+        members = all_members
+        if members_of is not None:
+            tick = members_of(ts)
+            if tick is not None:
+                ts_set = set(tick)
+                members = np.array([t in ts_set for t in mp.tickers])
+        cols, caps = select_universe(mp, pos, k, window_days, portfolio_spec["rebalancing_frequency"], members)
+        if len(cols) != k:
+            raise ValueError(f"universe has {len(cols)} assets, portfolio_spec['size'] is {k}")
+        col_idx[w] = cols
+        labels.append([mp.tickers[c] for c in cols])
+        # ref:986-988: the filtered prices of the window must be complete
+        lo_row = max(0, pos + 1 - window_days)
+        if np.isnan(mp.P[lo_row:pos + 1][:, cols]).any():
+            logger.error("Found NA values in the filtered stock prices.")
+            raise ValueError("The filtered stock prices contain NA values.")
+
+        # ---- daily window rows (ref:136-161, 31-62)
+        if freq == "daily":
+            first_price = max(0, pos - N + 1)
+            rows = np.arange(first_price + 1, pos + 1, dtype=np.int64)        # returns of prices first_price..pos
+            lab = mp.date_ns[first_price:pos + 1]
+        else:
+            b = int(mp.bin_of[pos])
+            first_bin = max(0, b - N + 1)
+            body = np.arange(first_bin + 1, b, dtype=np.int64)                 # returns between complete bins
+            with np.errstate(divide="ignore", invalid="ignore"):
+                prev = mp.R[b - 1] if b >= 1 else np.full(K, np.nan)
+                tail = np.log(mp.P[pos] / prev) if b > first_bin else None     # running bin: last price is P(date)
+            rows = body
+            if tail is not None:
+                tails.append(tail)
+                rows = np.concatenate([body, [base_rows + len(tails) - 1]])
+            lab = mp.label_ns[first_bin:b + 1]
+        if len(lab) >= 2:
+            mean_gap = _mean_gap_and_check(lab)
+            ridx = np.searchsorted(mp.rf_ns, lab[1:], side="right") - 1        # ffill on labels (ref:54)
+            rfv = np.where(ridx >= 0, mp.rf[np.maximum(ridx, 0)], np.nan)
+            adj = (1 + rfv) ** (mean_gap / 365) - 1                            # ref:48
+        else:
+            raise AssertionError("Unexpected large gap between return dates.")
+        # dropna (ref:60): a NaN risk-free value or a NaN return of a selected asset drops the row
+        if freq == "daily":
+            vals_nan = np.isnan(mp.L[rows][:, cols]).any(axis=1)
+        else:
+            block = np.vstack([mp.L[body][:, cols], tail[cols][None, :]]) if tail is not None else mp.L[body][:, cols]
+            vals_nan = np.isnan(block).any(axis=1)
+        keep = ~vals_nan & ~np.isnan(adj)
+        rows, adj = rows[keep], adj[keep]
+        n_rows[w] = len(rows)
+        row_idx[w, :len(rows)] = rows
+        rf_adj[w, :len(rows)] = adj
+
+        if conj:
+            # ---- intraday rows (ref:299-314): bars in (date + 1d - Delta, date + 1d]
+            span = _CALENDAR_DAYS[freq]
+            a = int(np.searchsorted(mp.hf_ns, d - span * _NS_PER_DAY + _NS_PER_DAY, side="right"))
+            # ref:972-974 truncates the intraday frame at 23:59:59 of the trading date before ref:311-312
+            end_of_day = pd.Timestamp(ts).replace(hour=23, minute=59, second=59).value
+            e = int(np.searchsorted(mp.hf_ns, min(d + _NS_PER_DAY, end_of_day), side="right"))
+            cand = np.arange(a + 1, e, dtype=np.int64)                          # the first bar's return is NaN (shift)
+            if len(cand):
+                cand = cand[~np.isnan(mp.H[cand][:, cols]).any(axis=1)]
+            hf_rows.append(cand)
+            hf_count[w] = len(cand)
+            # ---- prior weights and strength
+            if "vw" in strategy:
+                w0[w] = caps / caps.sum()                                       # ref:692-695 (already cap-descending)
+            else:
+                w0[w] = 1 / k                                                   # ref:670-672
+            n0[w] = _prior_strength(mp, mcm, d, ts, N, portfolio_spec["mcm_scaling"])
+
+    if (n_rows < 1).any():
+        raise ValueError("a rolling window has no usable return rows")
+    panel = mp.L if not tails else np.vstack([mp.L, np.asarray(tails)])
+    kw = dict(panel=np.nan_to_num(panel, nan=0.0), start=None, n_r=int(n_rows.max()),
+              row_idx=np.ascontiguousarray(row_idx[:, :int(n_rows.max())]), n_rows=n_rows, col_idx=col_idx,
+              rf_adj=np.ascontiguousarray(rf_adj[:, :int(n_rows.max())]))
+    if conj:
+        if (hf_count < 2).any():
+            raise ValueError("conjugate prior needs at least two intraday returns in the last period")
+        m = int(hf_count.max())
+        hidx = np.zeros((W, m), dtype=np.int32)
+        for w, r in enumerate(hf_rows):
+            hidx[w, :len(r)] = r
+        kw.update(hf_panel=np.nan_to_num(mp.H, nan=0.0), hf_start=None, hf_row_idx=hidx, hf_count=hf_count, m=m,
+                  w0=w0, n0=n0)
+    return kw, labels
+
+
+def _prior_strength(mp, mcm, d, ts, N, scaling):
+    """n0 = N * max(cur/avg, avg/cur) * mcm_scaling (ref:90-114, 247-267) from the cached MCM arrays."""
+    pos = int(np.searchsorted(mcm["ns"], d, side="right")) - 1
+    if pos < 0 or mcm["ns"][pos] != d:
+        logger.error(f"trading_date_ts {ts} is not the last date in the DataFrame.")
+        raise ValueError(f"trading_date_ts {ts} must be the last date in the DataFrame.")
+    cur = mcm["vals"][pos]
+    if mp.frequency == "daily":
+        window = mcm["vals"][max(0, pos - N + 1):pos + 1]
+    else:
+        b = int(np.searchsorted(mcm["rlabel_ns"], d, side="left"))
+        # running bin: last valid observation of the bin up to the date (resample().last() skips NaN)
+        lo = int(np.searchsorted(mcm["ns"], mcm["rlabel_ns"][b - 1], side="right")) if b >= 1 else 0
+        seg = mcm["vals"][lo:pos + 1]
+        seg = seg[~np.isnan(seg)]
+        tail = seg[-1] if len(seg) else np.nan
+        window = np.concatenate([mcm["rvals"][max(0, b - N + 1):b], [tail]])
+    window = window[~np.isnan(window)]                                        # DataFrame.mean skips NaN
+    avg = window.sum() / len(window)
+    frac = cur / avg if cur > avg else avg / cur
+    return N * frac * scaling

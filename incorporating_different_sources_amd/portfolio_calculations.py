@@ -27,9 +27,10 @@ import numpy as np
 import pandas as pd
 
 try:  # importable both as a package module and as a top-level `portfolio_calculations` (main.py style)
-    from . import _native
+    from . import _native, batch
 except ImportError:  # pragma: no cover - top-level import with the package directory on sys.path
     import _native  # type: ignore
+    import batch  # type: ignore
 
 logging_level = os.environ.get("LOGGING_LEVEL", logging.INFO)
 logging.basicConfig(level=logging_level)
@@ -544,44 +545,11 @@ def _pack_window(trading_date_ts, portfolio_spec, market_data):
     return item
 
 
-def _solve_packed(portfolio_spec, items):
-    """ONE device call for all packed windows of a spec: dense window-major panels + offsets."""
-    strategy = portfolio_spec["weighting_strategy"]
-    conj = strategy in _CONJUGATE
-    k = portfolio_spec["size"]
-    W = len(items)
-    for it in items:
-        if len(it["labels"]) != k:
-            raise ValueError(f"universe has {len(it['labels'])} assets, portfolio_spec['size'] is {k}")
-    n_rows = np.array([it["X"].shape[0] for it in items], dtype=np.int32)
-    n_r = int(n_rows.max())
-    start = np.concatenate([[0], np.cumsum(n_rows[:-1], dtype=np.int64)]).astype(np.int64)
-    panel = np.concatenate([it["X"] for it in items], axis=0)
-    rf_adj = np.zeros((W, n_r))
-    for i, it in enumerate(items):
-        rf_adj[i, : n_rows[i]] = it["rf"]
-    kw = dict(panel=panel, start=start, n_r=n_r, n_rows=n_rows, rf_adj=rf_adj)
-    m = 0
-    if conj:
-        counts = np.array([it["Y"].shape[0] for it in items], dtype=np.int32)
-        m = int(counts.max())
-        kw.update(hf_panel=np.concatenate([it["Y"] for it in items], axis=0),
-                  hf_start=np.concatenate([[0], np.cumsum(counts[:-1], dtype=np.int64)]).astype(np.int64),
-                  hf_count=counts, m=m, w0=np.stack([it["w0"] for it in items]),
-                  n0=np.array([it["n0"] for it in items]))
-    weights, status, aux = _native.posterior_batch("conjugate" if conj else "jeffreys", k,
-                                                   portfolio_spec["rolling_window"], portfolio_spec["risk_aversion"],
-                                                   **kw)
-    _raise_on_status(status)
-    out = []
-    for i, it in enumerate(items):
-        df = pd.DataFrame({"Weight": weights[i]}, index=pd.Index(it["labels"], name="Stock"))
-        out.append(df)
-    return out
-
-
 def calculate_portfolio_weights_batch(trading_dates, portfolio_spec, market_data):
-    """Weights for MANY rebalancing dates with one device call (the batch-native form of ref:941)."""
+    """Weights for MANY rebalancing dates with one device call (the batch-native form of ref:941).
+
+    Host side: `batch.pack_windows` turns the dates into panel + row/column-index arrays without
+    per-date pandas work; device side: one `posterior_batch` launch."""
     strategy = portfolio_spec["weighting_strategy"]
     if strategy in ("vw", "ew"):
         return [calculate_portfolio_weights(d, portfolio_spec, market_data) for d in trading_dates]
@@ -592,8 +560,26 @@ def calculate_portfolio_weights_batch(trading_dates, portfolio_spec, market_data
         raise ValueError("Unknown weights spec.")
     if not trading_dates:
         return []
-    items = [_pack_window(d, portfolio_spec, market_data) for d in trading_dates]
-    return _solve_packed(portfolio_spec, items)
+    members_of = _members_provider(market_data)
+    kw, labels = batch.pack_windows(list(trading_dates), portfolio_spec, market_data, members_of=members_of)
+    conj = strategy in _CONJUGATE
+    weights, status, aux = _native.posterior_batch("conjugate" if conj else "jeffreys", portfolio_spec["size"],
+                                                   portfolio_spec["rolling_window"], portfolio_spec["risk_aversion"],
+                                                   **kw)
+    _raise_on_status(status)
+    return [pd.DataFrame({"Weight": weights[i]}, index=pd.Index(labels[i], name="Stock")) for i in range(len(labels))]
+
+
+def _members_provider(market_data):
+    """Index membership per date for the batch packer: None = every column (synthetic panels)."""
+    provider = market_data.get("index_constituents") if isinstance(market_data, dict) else None
+    if callable(provider):
+        return provider
+    try:
+        import data_handling  # the reference's data layer, if the caller has it on sys.path
+        return lambda ts: data_handling.extract_unique_tickers(ts, ts)
+    except Exception:
+        return None
 
 
 def calculate_portfolio_weights(trading_date_ts, portfolio_spec, market_data):
