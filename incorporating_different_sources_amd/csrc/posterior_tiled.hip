@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
 
     // row sources
     const int* cols = A.col_idx ? A.col_idx + w * k : nullptr;
-    int mm = 0, nr = 0, nrows = SB;
+    int mm = 0, nr = 0;
     const int* hridx = nullptr; const int* dridx = nullptr;
     long long hfirst = 0, dfirst = 0;
     const double* rf = nullptr;
@@ -157,34 +157,8 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
         dridx = A.row_idx ? A.row_idx + w * (long long)A.n_r : nullptr;
         dfirst = A.start ? A.start[w] : 0;
         rf = A.rf_adj ? A.rf_adj + w * (long long)A.n_r : nullptr;
-        nrows = mm + nr;
     }
     const double* rinv = ws.rinv + (wl * ws.NSB + j) * (long long)(SB * SB);
-
-    // value of staged element (row r, half h = 0: A columns / 1: B columns, local column c)
-    auto fetch = [&](int r, int h, int c) -> double {
-        if (MODE == MODE_GRAM) {
-            const int gc = 64 * (h ? SJ : SI) + c;
-            const bool hf = r < mm;
-            if (gc < k) {
-                const int pc = cols ? cols[gc] : gc;
-                if (hf) {
-                    const long long row = hridx ? (long long)hridx[r] : hfirst + r;
-                    return sqs * (A.hf_panel[row * (long long)A.hf_ld + pc] - ybar[gc]);
-                }
-                const int rd = r - mm;
-                const long long row = dridx ? (long long)dridx[rd] : dfirst + rd;
-                return A.panel[row * (long long)A.panel_ld + pc] - (rf ? rf[rd] : 0.0);
-            }
-            if (gc == k) return hf ? zc[r] : 1.0;
-            return 0.0;
-        } else if (MODE == MODE_TRSM) {
-            if (h == 0) return rinv[r * SB + c];                              // k-major image of R_jj^-T
-            return M[(long long)(64 * j + r) * KP + 64 * SJ + c];
-        } else {
-            return M[(long long)(64 * j + r) * KP + 64 * (h ? SJ : SI) + c];
-        }
-    };
 
     d4 acc[4];
 #pragma unroll
@@ -197,20 +171,83 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
                 acc[b][r] = M[(long long)(64 * SI + 16 * wv + fq + 4 * r) * KP + 64 * SJ + 16 * b + fr];
     }
 
-    const int nchunks = (nrows + CH - 1) / CH;
+    // Staging geometry: 16 threads per row, thread (srow, cb) handles local columns cb + 16 i of the
+    // A half (i < 4) and of the B half (i >= 4).  Per-thread column constants are fixed for the whole
+    // kernel; the chunk loop issues RAW loads only (no select, no arithmetic on a loaded value before
+    // the MFMA block) so that the next chunk's loads stay in flight under the MFMAs.
     const int srow = tid >> 4, cb = tid & 15;
-    double v[8];
-    auto load = [&](int ch) {
-        const int r = ch * CH + srow;
-        const bool rv = r < nrows;
+    int pcol[8];            // GRAM: panel column (clamped) ; TRSM/SYRK: arena / rinv column
+    double yb[8];           // GRAM: intraday column mean of that column
+    bool cval[8], cbord[8]; // GRAM: real asset column / border column
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = rv ? fetch(r, i >> 2, cb + 16 * (i & 3)) : 0.0;
+    for (int i = 0; i < 8; ++i) {
+        const int c = cb + 16 * (i & 3);
+        if (MODE == MODE_GRAM) {
+            const int gc = 64 * ((i >> 2) ? SJ : SI) + c;
+            cval[i] = gc < k;
+            cbord[i] = gc == k;
+            const int gcl = cval[i] ? gc : k - 1;
+            pcol[i] = gcl;
+            yb[i] = cval[i] ? ybar[gcl] : 0.0;
+        } else {
+            cval[i] = true; cbord[i] = false; yb[i] = 0.0;
+            pcol[i] = (MODE == MODE_TRSM && (i >> 2) == 0) ? c : 64 * ((i >> 2) ? SJ : SI) + c;
+        }
+    }
+    if (MODE == MODE_GRAM && cols) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pcol[i] = cols[pcol[i]];
+    }
+    // GRAM rows: [intraday rows, padded to whole chunks][daily rows]; a chunk is purely one kind
+    const int hchunks = (mm + CH - 1) / CH;
+    const int nchunks = (MODE == MODE_GRAM) ? hchunks + (nr + CH - 1) / CH : SB / CH;
+    double v[8];
+    double rowc = 0.0;      // per-row constant: border entry (intraday) / risk-free adjustment (daily)
+    bool rowv = false;
+    auto load = [&](int ch) {
+        if (MODE == MODE_GRAM) {
+            const bool hf = ch < hchunks;
+            const int r = (hf ? ch : ch - hchunks) * CH + srow;
+            const int cnt = hf ? mm : nr;
+            rowv = r < cnt;
+            const int rc = rowv ? r : cnt - 1;
+            const double* base;
+            if (hf) {
+                const long long row = hridx ? (long long)hridx[rc] : hfirst + rc;
+                base = A.hf_panel + row * (long long)A.hf_ld;
+                rowc = zc[rc];
+            } else {
+                const long long row = dridx ? (long long)dridx[rc] : dfirst + rc;
+                base = A.panel + row * (long long)A.panel_ld;
+                rowc = rf ? rf[rc] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = base[pcol[i]];
+        } else {
+            const int r = ch * CH + srow;
+            const double* rowA = (MODE == MODE_TRSM) ? rinv + r * SB : M + (long long)(64 * j + r) * KP;
+            const double* rowB = M + (long long)(64 * j + r) * KP;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = rowA[pcol[i]];
+#pragma unroll
+            for (int i = 4; i < 8; ++i) v[i] = rowB[pcol[i]];
+        }
     };
-    auto store = [&](double* buf) {
+    auto store = [&](double* buf, int ch) {
+        if (MODE == MODE_GRAM) {
+            const bool hf = ch < hchunks;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                double x;
+                if (hf) x = cval[i] ? sqs * (v[i] - yb[i]) : (cbord[i] ? rowc : 0.0);   // sqrt(s) (y - ybar) | c sqrt(s) z_r
+                else x = cval[i] ? v[i] - rowc : (cbord[i] ? 1.0 : 0.0);                // x - rf (ref:57) | 1
+                v[i] = rowv ? x : 0.0;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) buf[srow * LDX + 64 * (i >> 2) + cb + 16 * (i & 3)] = v[i];
     };
-    if (nchunks > 0) { load(0); store(lds); }
+    if (nchunks > 0) { load(0); store(lds, 0); }
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         double* cur = lds + (ch & 1) * CH * LDX;
@@ -227,7 +264,7 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
             for (int b = 0; b < 4; ++b)
                 acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, lb[4 * s4 * LDX + 64 + 16 * b], acc[b], 0, 0, 0);
         }
-        if (more) store(nxt);
+        if (more) store(nxt, ch + 1);
         __syncthreads();
     }
 #pragma unroll
