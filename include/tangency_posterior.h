@@ -53,6 +53,10 @@ extern "C" {
 
 #define TP_AUX_STRIDE 8 /* doubles per window in `aux`: n0, n1, c, q0, q1, n1-q1, 0, 0 */
 
+/* tp_params_t.flags */
+#define TP_FLAG_CENTER_BY_ROWS 1 /* Jeffreys scatter T - t t'/n_w with n_w = the rows window w actually
+                                   uses instead of N: (n_w - 1) x the sample covariance (ref:876, 917) */
+
 typedef struct tp_handle_s* tp_handle_t;
 typedef struct tp_batch_s* tp_batch_t;
 
@@ -63,7 +67,7 @@ typedef struct tp_params {
     int32_t n_r;      /* max rows of excess returns per window (= N-1 without NaN drops, ref:60) */
     int32_t m;        /* max intraday returns per window (conjugate only; ref:314) */
     int32_t strategy; /* TP_STRATEGY_* */
-    int32_t reserved;
+    int32_t flags;    /* TP_FLAG_* */
     double gamma;     /* portfolio_spec["risk_aversion"]   (ref:836, 849) */
 } tp_params_t;
 
@@ -112,7 +116,14 @@ int tp_device_info(tp_handle_t h, char* name, int name_len, int* compute_units, 
  * (ref:1184 -> ref:941) for all rebalancing dates of a backtest at once. */
 int tp_batch_create(tp_handle_t h, const tp_params_t* p, int64_t W, tp_batch_t* out);
 int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in);   /* H2D, synchronous */
+/* Optional right-hand side [W x k] replacing the border column (t for Jeffreys, c S0 w0 + t for the
+ * conjugate posterior) in every later tp_batch_run: the weights become (matrix)^-1 rhs / gamma.  NULL
+ * restores the default.  Binds the V^-1 1 / V^-1 mu solves of calculate_jorion_portfolio (ref:880-891). */
+int tp_batch_set_rhs(tp_batch_t b, const double* rhs);
 int tp_batch_run(tp_batch_t b);                             /* async on the handle's stream; HIP-event timed */
+/* The right-hand side each window was solved for in the last run (default: t = X'1, ref:222, resp.
+ * c S0 w0 + t, ref:489); runs the batch once if it has not kept it yet. */
+int tp_batch_download_rhs(tp_batch_t b, double* rhs_out /* [W x k] */);                             /* async on the handle's stream; HIP-event timed */
 int tp_batch_download(tp_batch_t b, double* weights /* [W x k] */, int32_t* status /* [W] */,
                       double* aux /* optional [W x TP_AUX_STRIDE] */); /* waits for the stream, D2H */
 int tp_batch_download_S1(tp_batch_t b, int64_t w, double* S1 /* [k x k] */); /* posterior scale matrix

@@ -25,12 +25,13 @@ STRATEGY_CONJUGATE = 0
 STRATEGY_JEFFREYS = 1
 STATUS_OK, STATUS_NOT_PD, STATUS_NONFINITE, STATUS_BAD_DENOM = 0, 1, 2, 3
 AUX_STRIDE = 8
+FLAG_CENTER_BY_ROWS = 1
 UNIQUE_ID_BYTES = 128
 
 # every symbol include/tangency_posterior.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTS = [
     "tp_version", "tp_max_assets", "tp_device_count", "tp_create", "tp_destroy", "tp_last_error", "tp_device_info",
-    "tp_batch_create", "tp_batch_upload", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1", "tp_batch_download_matrix", "tp_batch_debug_stamps",
+    "tp_batch_create", "tp_batch_upload", "tp_batch_set_rhs", "tp_batch_download_rhs", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1", "tp_batch_download_matrix", "tp_batch_debug_stamps",
     "tp_batch_destroy", "tp_posterior_batch", "tp_synchronize", "tp_last_timing", "tp_region_begin",
     "tp_region_end", "tp_last_launch", "tp_comm_unique_id", "tp_comm_init", "tp_comm_destroy",
     "tp_batch_gather", "tp_batch_download_gathered",
@@ -45,7 +46,7 @@ class TangencyError(RuntimeError):
 
 class tp_params_t(ctypes.Structure):
     _fields_ = [("k", c_int32), ("N", c_int32), ("n_r", c_int32), ("m", c_int32), ("strategy", c_int32),
-                ("reserved", c_int32), ("gamma", c_double)]
+                ("flags", c_int32), ("gamma", c_double)]
 
 
 class tp_inputs_t(ctypes.Structure):
@@ -72,6 +73,8 @@ def _load():
     lib.tp_device_info.argtypes = [c_void_p, c_char_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int64)]
     lib.tp_batch_create.argtypes = [c_void_p, POINTER(tp_params_t), c_int64, POINTER(c_void_p)]
     lib.tp_batch_upload.argtypes = [c_void_p, POINTER(tp_inputs_t)]
+    lib.tp_batch_set_rhs.argtypes = [c_void_p, POINTER(c_double)]
+    lib.tp_batch_download_rhs.argtypes = [c_void_p, POINTER(c_double)]
     lib.tp_batch_run.argtypes = [c_void_p]
     lib.tp_batch_download.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int32), POINTER(c_double)]
     lib.tp_batch_download_S1.argtypes = [c_void_p, c_int64, POINTER(c_double)]
@@ -197,17 +200,17 @@ class Device:
         self._check(lib.tp_comm_destroy(self._h))
 
     # ---- batches ------------------------------------------------------------------------------
-    def batch(self, strategy, k, N, n_r, gamma, W, m=0) -> "Batch":
-        return Batch(self, strategy, k, N, n_r, gamma, W, m)
+    def batch(self, strategy, k, N, n_r, gamma, W, m=0, flags=0) -> "Batch":
+        return Batch(self, strategy, k, N, n_r, gamma, W, m, flags)
 
 
 class Batch:
     """W windows resident in HBM (`tp_batch_t`)."""
 
-    def __init__(self, dev: Device, strategy, k, N, n_r, gamma, W, m=0):
+    def __init__(self, dev: Device, strategy, k, N, n_r, gamma, W, m=0, flags=0):
         self.dev = dev
         strat = {"conjugate": STRATEGY_CONJUGATE, "jeffreys": STRATEGY_JEFFREYS}.get(strategy, strategy)
-        self.params = tp_params_t(int(k), int(N), int(n_r), int(m), int(strat), 0, float(gamma))
+        self.params = tp_params_t(int(k), int(N), int(n_r), int(m), int(strat), int(flags), float(gamma))
         self.W, self.k, self.n_r, self.m = int(W), int(k), int(n_r), int(m)
         self._b = c_void_p()
         dev._check(lib.tp_batch_create(dev._h, ctypes.byref(self.params), self.W, ctypes.byref(self._b)))
@@ -254,6 +257,18 @@ class Batch:
         self.dev._check(lib.tp_batch_upload(self._b, ctypes.byref(inp)))
         self._keep = None
         return self
+
+    def set_rhs(self, rhs):
+        """Right-hand side [W x k] in place of the border column (None: default t / c S0 w0 + t)."""
+        r = _arr(rhs, np.float64, (self.W, self.k), "rhs")
+        self.dev._check(lib.tp_batch_set_rhs(self._b, _ptr(r, c_double)))
+        return self
+
+    def download_rhs(self) -> np.ndarray:
+        """[W x k] right-hand sides the windows were solved for (t = X'1 by default)."""
+        out = np.empty((self.W, self.k), dtype=np.float64)
+        self.dev._check(lib.tp_batch_download_rhs(self._b, _ptr(out, c_double)))
+        return out
 
     def run(self):
         self.dev._check(lib.tp_batch_run(self._b))
@@ -321,12 +336,14 @@ def default_device() -> Device:
 
 def posterior_batch(strategy, k, N, gamma, panel, start=None, n_r=None, hf_panel=None, hf_start=None, m=0,
                     w0=None, n0=None, row_idx=None, n_rows=None, col_idx=None, rf_adj=None,
-                    hf_row_idx=None, hf_count=None, device: Device | None = None, want_aux=True):
+                    hf_row_idx=None, hf_count=None, device: Device | None = None, want_aux=True, rhs=None, flags=0):
     """Upload + run + download.  Same argument meaning as `oracle.posterior_batch` (tests compare them)."""
     dev = device or default_device()
     W = len(start) if start is not None else len(row_idx)
-    b = Batch(dev, strategy, k, N, n_r, gamma, W, m or 0)
+    b = Batch(dev, strategy, k, N, n_r, gamma, W, m or 0, flags)
     try:
+        if rhs is not None:
+            b.set_rhs(rhs)
         b.upload(panel, start=start, hf_panel=hf_panel, hf_start=hf_start, w0=w0, n0=n0, row_idx=row_idx,
                  n_rows=n_rows, col_idx=col_idx, rf_adj=rf_adj, hf_row_idx=hf_row_idx, hf_count=hf_count)
         b.run()

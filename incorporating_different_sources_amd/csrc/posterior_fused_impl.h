@@ -563,7 +563,7 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
     if (!conj) {
         // ---- phase E: J = T - t t'/N (ref:600-601); t stays in the border column (ref:606 rhs)
         __syncthreads();
-        const double invN = 1.0 / (double)A.N;
+        const double invN = 1.0 / (double)(A.center_rows ? (A.n_rows ? A.n_rows[w] : A.n_r) : A.N);
         wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
             for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
                 constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
@@ -577,7 +577,44 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
             });
         });
     }
+    if (A.rhs != nullptr) {
+        // caller-supplied right-hand side in place of the border column (tp_batch_set_rhs)
+        wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
+            for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
+                constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
+                if constexpr (J == kI) {
+                    if (fr == kc) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int gi = 16 * I + fq + 4 * r;
+                            const int gl = gi < k ? gi : k - 1;
+                            const double x = A.rhs[w * k + gl];
+                            acc[s][r] = (gi < k) ? x : 0.0;
+                        }
+                    }
+                }
+            });
+        });
+    }
 
+    if (A.out_rhs != nullptr) {
+        // the right-hand side this window is solved for (t = X'1 for Jeffreys: ref:222), for callers
+        // that need it next to the solution (tp_batch_download_rhs)
+        wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
+            for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
+                constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
+                if constexpr (J == kI) {
+                    if (fr == kc) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int gi = 16 * I + fq + 4 * r;
+                            if (gi < k) A.out_rhs[w * k + gi] = acc[s][r];
+                        }
+                    }
+                }
+            });
+        });
+    }
     }
     if (dbg == 3) dump_matrix();
 

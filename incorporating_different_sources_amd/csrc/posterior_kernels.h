@@ -22,9 +22,11 @@ struct tp_kargs_t {
     const int* hf_count;
     const double* w0;
     const double* n0;
+    const double* rhs;    // optional [W x k]: replaces the border column before the factorisation
     double* weights;
     int* status;
     double* aux;
+    double* out_rhs;      // optional [W x k]: the right-hand side (border column) each window was solved for
     long long* stamps;    // diagnostic builds only: [w_count x 8] s_memtime stamps per window
     double* dbg_S1;       // optional [k*k + k]: S1 (or J) and the right-hand side of window dbg_w
     long long dbg_w;
@@ -32,6 +34,7 @@ struct tp_kargs_t {
     long long w_first, w_count;
     int panel_ld, hf_ld;
     int k, N, n_r, m, strategy;
+    int center_rows;      // Jeffreys: divide t t' by the window's row count instead of N
     double gamma;
 };
 

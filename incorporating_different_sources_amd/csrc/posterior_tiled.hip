@@ -282,7 +282,8 @@ __global__ void __launch_bounds__(NTHREADS) tiled_rank1_kernel(const tp_kargs_t 
     double* M = ws.arena + wl * (long long)KP * KP;
     int SI, SJ;
     pair_decode(blockIdx.y, NS, SI, SJ);
-    const double invN = 1.0 / (double)A.N;
+    const long long w = A.w_first + wl;
+    const double invN = 1.0 / (double)(A.center_rows ? (A.n_rows ? A.n_rows[w] : A.n_r) : A.N);
     for (int e = tid; e < SB * SB; e += NTHREADS) {
         const int gi = 64 * SI + (e >> 6), gj = 64 * SJ + (e & 63);
         if (gi < k && gj < k) {
@@ -434,6 +435,10 @@ __global__ void __launch_bounds__(NTHREADS) tiled_clear_kernel(const tp_kargs_t 
     const int k = A.k, KP = ws.KP;
     double* M = ws.arena + wl * (long long)KP * KP;
     for (int e = threadIdx.x; e < (KP - k) * KP; e += NTHREADS) M[(long long)k * KP + e] = 0.0;
+    if (A.rhs != nullptr)     // caller-supplied right-hand side in place of the border column
+        for (int i = threadIdx.x; i < k; i += NTHREADS) M[(long long)i * KP + k] = A.rhs[(A.w_first + wl) * k + i];
+    if (A.out_rhs != nullptr)
+        for (int i = threadIdx.x; i < k; i += NTHREADS) A.out_rhs[(A.w_first + wl) * k + i] = M[(long long)i * KP + k];
     if (threadIdx.x == 0) ws.flags[wl] = 0;
 }
 

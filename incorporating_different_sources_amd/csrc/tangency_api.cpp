@@ -46,7 +46,7 @@ struct tp_batch_s {
     int64_t W = 0;
     int panel_ld = 0, hf_ld = 0;
     DevBuf panel, start, row_idx, n_rows, col_idx, rf_adj, hf_panel, hf_start, hf_row_idx, hf_count, w0, n0;
-    DevBuf weights, status, aux, dbg, gather_w, gather_s, stamps;
+    DevBuf weights, status, aux, dbg, gather_w, gather_s, stamps, rhs, out_rhs;
     DevBuf t_arena, t_rinv, t_ybar, t_zc, t_scal, t_flags;   // large-k path workspace
     int64_t tiled_capacity = 0;                               // windows in flight per sub-batch
     bool uploaded = false;
@@ -126,9 +126,12 @@ tp_kargs_t make_kargs(tp_batch_t b) {
     a.hf_count = (const int*)b->hf_count.p;
     a.w0 = (const double*)b->w0.p;
     a.n0 = (const double*)b->n0.p;
+    a.rhs = (const double*)b->rhs.p;
+    a.center_rows = (b->p.flags & TP_FLAG_CENTER_BY_ROWS) ? 1 : 0;
     a.weights = (double*)b->weights.p;
     a.status = (int*)b->status.p;
     a.aux = (double*)b->aux.p;
+    a.out_rhs = (double*)b->out_rhs.p;
     a.stamps = (long long*)b->stamps.p;
     a.dbg_S1 = nullptr;
     a.dbg_w = -1;
@@ -251,6 +254,8 @@ int launch(tp_batch_t b, const tp_kargs_t& a, int64_t count, bool timed) {
 
 }  // namespace
 
+static int harvest_kernel_time(tp_handle_t h);
+
 extern "C" {
 
 const char* tp_version(void) { return "tangency-posterior 0.2.0 (gfx950, fp64 MFMA: register-tile kernel k<=239, tiled pipeline k<=2047)"; }
@@ -343,7 +348,7 @@ int tp_batch_destroy(tp_batch_t b) {
     (void)hipStreamSynchronize(b->h->stream);
     DevBuf* all[] = {&b->panel, &b->start, &b->row_idx, &b->n_rows, &b->col_idx, &b->rf_adj, &b->hf_panel, &b->hf_start,
                      &b->hf_row_idx, &b->hf_count, &b->w0, &b->n0, &b->weights, &b->status, &b->aux, &b->dbg,
-                     &b->gather_w, &b->gather_s, &b->stamps, &b->t_arena, &b->t_rinv, &b->t_ybar, &b->t_zc,
+                     &b->gather_w, &b->gather_s, &b->stamps, &b->rhs, &b->out_rhs, &b->t_arena, &b->t_rinv, &b->t_ybar, &b->t_zc,
                      &b->t_scal, &b->t_flags};
     for (DevBuf* d : all) release(*d);
     delete b;
@@ -386,6 +391,36 @@ int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in) {
     h->h2d_ms = ms;
     b->uploaded = true;
     return TP_OK;
+}
+
+int tp_batch_set_rhs(tp_batch_t b, const double* rhs) {
+    if (!b) return TP_ERR_INVALID;
+    tp_handle_t h = b->h;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));       // a running launch may still read the old one
+    int rc = put(h, b->rhs, rhs, sizeof(double) * (size_t)b->W * b->p.k);
+    if (rc != TP_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return TP_OK;
+}
+
+int tp_batch_download_rhs(tp_batch_t b, double* rhs_out) {
+    if (!b || !rhs_out) return TP_ERR_INVALID;
+    tp_handle_t h = b->h;
+    if (!b->uploaded) return fail(h, TP_ERR_INVALID, "tp_batch_download_rhs before tp_batch_upload");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t bytes = sizeof(double) * (size_t)b->W * b->p.k;
+    const bool fresh = b->out_rhs.p == nullptr;
+    int rc = ensure(h, b->out_rhs, bytes);
+    if (rc != TP_OK) return rc;
+    if (fresh) {                      // the buffer did not exist during earlier runs: produce it now
+        rc = tp_batch_run(b);
+        if (rc != TP_OK) return rc;
+    }
+    HIP_TRY(h, hipMemcpyAsync(rhs_out, b->out_rhs.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return harvest_kernel_time(h);
 }
 
 int tp_batch_run(tp_batch_t b) {

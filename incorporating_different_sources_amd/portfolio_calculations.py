@@ -14,8 +14,9 @@ pandas:
 
 There is no CPU fallback for the estimators: without `libtangency.so` and a gfx950 GPU they raise.
 The passive weightings (vw / ew, ref:661-701) are host-side, as they are inputs (prior weights w0 and
-the comparison portfolio), not part of the accelerated path.  Shrinkage, Black-Litterman, Jorion and
-Greyserman (ref:703-817, 851-938) are outside the scope of this build and raise NotImplementedError.
+the comparison portfolio), not part of the accelerated path.  Jorion's Bayes-Stein portfolio (ref:851-895)
+reuses the device's scatter + Cholesky solve with two right-hand sides.  Shrinkage, Black-Litterman and
+Greyserman (ref:703-817, 897-938) are outside the scope of this build and raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -42,7 +43,7 @@ logger = logging.getLogger(__name__)
 CHECK = False
 
 _CONJUGATE = ("conjugate_hf_vix_vw", "conjugate_hf_vix_ew", "conjugate_hf_epu_vw", "conjugate_hf_epu_ew")
-_OUT_OF_SCOPE = ("shrinkage", "black_litterman", "jorion", "greyserman")
+_OUT_OF_SCOPE = ("shrinkage", "black_litterman", "greyserman")
 _RESAMPLE_RULE = {"weekly": "W", "monthly": "ME"}
 
 
@@ -452,8 +453,60 @@ def _not_in_scope(name):
 
 calculate_shrinkage_portfolio = _not_in_scope("calculate_shrinkage_portfolio")
 calculate_black_litterman_portfolio = _not_in_scope("calculate_black_litterman_portfolio")
-calculate_jorion_portfolio = _not_in_scope("calculate_jorion_portfolio")
 calculate_greyserman_portfolio = _not_in_scope("calculate_greyserman_portfolio")
+
+
+def _jorion_from_solves(x_t, x_one, t, T, N, gamma):
+    """Jorion's Bayes-Stein weights (ref:869-893) from two device solves with the centred scatter
+    J = (T-1) V_hat:  x_t = J^-1 t (t = X'1 = T mu_hat) and x_one = J^-1 1.  V_bar = T/(T-N-2) V_hat, so
+    V_bar^-1 = kappa J^-1 with kappa = (T-N-2)(T-1)/T; V_PJ is V_bar scaled plus a multiple of 11', whose
+    inverse follows from V_bar^-1 1 by Sherman-Morrison instead of the reference's second LU inverse.
+    Vectorised over windows: x_t, x_one, t are [W x N], T is [W]."""
+    T = np.asarray(T, dtype=np.float64)[:, None]
+    kappa = (T - N - 2) * (T - 1) / T
+    mu = t / T
+    a = kappa * x_t / T                    # V_bar^-1 mu_hat
+    b = kappa * x_one                      # V_bar^-1 1
+    s_bb = b.sum(axis=1, keepdims=True)
+    s_ab = a.sum(axis=1, keepdims=True)
+    s_aa = (mu * a).sum(axis=1, keepdims=True)
+    mu_g = s_ab / s_bb                                                   # ref:882
+    q = s_aa - 2 * mu_g * s_ab + mu_g ** 2 * s_bb                        # d' V_bar^-1 d
+    lam = (N + 2) / q                                                    # ref:885
+    v = (N + 2) / ((N + 2) + T * q)                                      # ref:887
+    alpha = 1 + 1 / (T + lam)                                            # ref:888: V_PJ = alpha V_bar + beta 11'
+    beta = lam / (T * (T + 1 + lam)) / s_bb
+    g = (1 - v) * a + v * mu_g * b                                       # V_bar^-1 mu_PJ (ref:889)
+    sol = g / alpha - (beta / alpha ** 2) * b * g.sum(axis=1, keepdims=True) / (1 + (beta / alpha) * s_bb)
+    return sol / gamma                                                   # ref:893
+
+
+def _jorion_batch(kw, gamma, k, N):
+    """Two launches over the same resident batch: right-hand side t (default) and right-hand side 1."""
+    dev = _native.default_device()
+    W = len(kw["n_rows"])
+    b = _native.Batch(dev, "jeffreys", k, N, kw["n_r"], 1.0, W, 0, flags=_native.FLAG_CENTER_BY_ROWS)
+    try:
+        b.upload(**{key: val for key, val in kw.items() if key not in ("n_r", "m")})
+        t = b.download_rhs()
+        x_t, status, _ = b.run().download(want_aux=False)
+        _raise_on_status(status)
+        b.set_rhs(np.ones((W, k)))
+        x_one, status, _ = b.run().download(want_aux=False)
+        _raise_on_status(status)
+    finally:
+        b.close()
+    return _jorion_from_solves(x_t, x_one, t, kw["n_rows"], k, gamma)
+
+
+def calculate_jorion_portfolio(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df):
+    """Jorion hyper-parameter portfolio (ref:851-895): the two SPD solves run on the device."""
+    X, rf_rows, labels = _daily_window_arrays(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df)
+    k = len(labels)
+    kw = dict(panel=X, start=np.zeros(1, np.int64), n_r=X.shape[0], n_rows=np.array([X.shape[0]], np.int32),
+              rf_adj=rf_rows[None, :])
+    w = _jorion_batch(kw, portfolio_spec["risk_aversion"], k, portfolio_spec["rolling_window"])
+    return pd.DataFrame({"Weight": w[0]}, index=pd.Index(labels, name="Stock"))
 
 
 # ======================================================================================================
@@ -555,13 +608,17 @@ def calculate_portfolio_weights_batch(trading_dates, portfolio_spec, market_data
         return [calculate_portfolio_weights(d, portfolio_spec, market_data) for d in trading_dates]
     if strategy in _OUT_OF_SCOPE:
         _not_in_scope(f"calculate_{strategy}_portfolio")()
-    if strategy not in _CONJUGATE and strategy != "jeffreys":
+    if strategy not in _CONJUGATE and strategy not in ("jeffreys", "jorion"):
         logger.error("Unknown weights spec.")
         raise ValueError("Unknown weights spec.")
     if not trading_dates:
         return []
     members_of = _members_provider(market_data)
     kw, labels = batch.pack_windows(list(trading_dates), portfolio_spec, market_data, members_of=members_of)
+    if strategy == "jorion":
+        kw.pop("start", None)
+        weights = _jorion_batch(kw, portfolio_spec["risk_aversion"], portfolio_spec["size"], portfolio_spec["rolling_window"])
+        return [pd.DataFrame({"Weight": weights[i]}, index=pd.Index(labels[i], name="Stock")) for i in range(len(labels))]
     conj = strategy in _CONJUGATE
     weights, status, aux = _native.posterior_batch("conjugate" if conj else "jeffreys", portfolio_spec["size"],
                                                    portfolio_spec["rolling_window"], portfolio_spec["risk_aversion"],
@@ -720,7 +777,7 @@ def backtest_portfolio(portfolio_spec, ts_start_date, ts_end_date, market_data):
     trading_dates = [ts for ts in trading_dates if ts_start_date <= ts <= ts_end_date]
     strategy = portfolio_spec["weighting_strategy"]
     precomputed = {}
-    if strategy in _CONJUGATE or strategy == "jeffreys":
+    if strategy in _CONJUGATE or strategy in ("jeffreys", "jorion"):
         rebalance_dates = rebalancing_schedule(trading_dates, portfolio_spec["rebalancing_frequency"])
         frames = calculate_portfolio_weights_batch(rebalance_dates, portfolio_spec, market_data)
         precomputed = dict(zip(rebalance_dates, frames))

@@ -162,7 +162,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     holder = {"tickers": []}
     pc, ps = import_reference(holder)
-    which = sys.argv[1:] or ["single", "backtest", "specs", "large"]
+    which = sys.argv[1:] or ["single", "backtest", "specs", "large", "jorion"]
     conj = ["conjugate_hf_vix_vw", "conjugate_hf_vix_ew"]
     if "single" in which:
         # BASELINE config 1 shapes (k=10, N=60), 4 windows, all intermediates + inputs stored
@@ -190,6 +190,25 @@ def main():
                      8, 30, "weekly", "monthly", 260, 12, 20240011, 170, rf_nan_every=17)
         gen_backtest(pc, holder, "backtest_k6_n9_monthly_weekly", ["conjugate_hf_epu_vw", "jeffreys", "ew"],
                      6, 9, "monthly", "weekly", 300, 9, 20240012, 230)
+    if "jorion" in which:
+        # F3: Jorion's Bayes-Stein portfolio (ref:851-895) on single windows and in a backtest
+        out = {}
+        for k, N, seed in ((10, 60, 20240001), (33, 80, 20240033), (100, 250, 20240002)):
+            inp = synthetic.make_kernel_inputs(k, N, 2, seed)
+            tickers = [f"A{i:04d}" for i in range(k)]
+            for w in range(2):
+                date, prices_df, intraday_df, caps_df, rf_df = window_frames(inp, w, tickers)
+                spec = {"weighting_strategy": "jorion", "size": k, "risk_aversion": 5, "rolling_window": N,
+                        "rolling_window_frequency": "daily", "rebalancing_frequency": "daily"}
+                wts = pc.calculate_jorion_portfolio(spec, date, prices_df, rf_df)
+                out[f"k{k}_n{N}_w{w}_weights"] = wts["Weight"].to_numpy()
+            out[f"k{k}_n{N}_seed"] = seed
+        np.savez_compressed(os.path.join(OUT, "jorion_single.npz"), **out)
+        print("wrote jorion_single.npz")
+        gen_backtest(pc, holder, "backtest_k10_n60_daily_jorion", ["jorion"], 10, 60, "daily", "daily", 165, 14,
+                     20240001, 65)
+        gen_backtest(pc, holder, "backtest_k8_n30_weekly_monthly_jorion", ["jorion"], 8, 30, "weekly", "monthly",
+                     260, 12, 20240011, 170, rf_nan_every=17)
     if "specs" in which:
         specs = ps.create_portfolio_specs()
         keys = list(specs.keys())

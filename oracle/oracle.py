@@ -139,18 +139,19 @@ def conjugate_window(X, Y, w0, n0, N, k, gamma, return_aux=False):
 
 # ----------------------------------------------------------------------------------------------
 # Jeffreys posterior (ref:580-608, 838-849)
-def mean_jeffreys_posterior_nu(X: np.ndarray, N: int) -> np.ndarray:
-    """ref:600-606  J = T - (1/N) t t' ;  nu = inv(J) . t   (N = rolling_window, not n_r: Appendix B-Q1)."""
+def mean_jeffreys_posterior_nu(X: np.ndarray, N: int, rhs=None) -> np.ndarray:
+    """ref:600-606  J = T - (1/N) t t' ;  nu = inv(J) . t   (N = rolling_window, not n_r: Appendix B-Q1).
+    `rhs` replaces t (the C-ABI's tp_batch_set_rhs)."""
     T = canonical_statistics_T(X)
     t = canonical_statistics_t(X)
     J = T - 1 / N * np.outer(t, t)
-    return np.linalg.inv(J) @ t
+    return np.linalg.inv(J) @ (t if rhs is None else rhs)
 
 
-def jeffreys_window(X, N, gamma, return_aux=False):
+def jeffreys_window(X, N, gamma, return_aux=False, rhs=None):
     """ref:838-849 (calculate_jeffreys_portfolio): weights = nu / gamma."""
     X = np.asarray(X, dtype=np.float64)
-    nu = mean_jeffreys_posterior_nu(X, N)
+    nu = mean_jeffreys_posterior_nu(X, N, rhs)
     weights = 1 / gamma * nu
     if return_aux:
         T = canonical_statistics_T(X)
@@ -160,10 +161,30 @@ def jeffreys_window(X, N, gamma, return_aux=False):
 
 
 # ----------------------------------------------------------------------------------------------
+# Jorion hyper-parameter (Bayes-Stein) portfolio (ref:851-895), SURVEY §8(f) row F3
+def jorion_window(X, gamma):
+    """ref:869-893 with the notation of the reference: N assets, T return rows."""
+    X = np.asarray(X, dtype=np.float64)
+    T, N = X.shape
+    mu = X.mean(axis=0)                                             # ref:873
+    V = np.cov(X, rowvar=False, ddof=1).reshape(N, N)               # ref:876
+    Vbar = T / (T - N - 2) * V                                      # ref:879
+    Vbi = np.linalg.inv(Vbar)                                       # ref:880
+    one = np.ones(N)
+    mu_g = (one @ Vbi @ mu) / (one @ Vbi @ one)                     # ref:882
+    d = mu - mu_g * one
+    lam = (N + 2) / (d @ Vbi @ d)                                   # ref:885
+    v = (N + 2) / ((N + 2) + T * (d @ Vbi @ d))                     # ref:887
+    V_PJ = (1 + 1 / (T + lam)) * Vbar + lam / (T * (T + 1 + lam)) * np.outer(one, one) / (one @ Vbi @ one)   # ref:888
+    mu_PJ = (1 - v) * mu + v * mu_g * one                           # ref:889
+    return 1 / gamma * (np.linalg.inv(V_PJ) @ mu_PJ)                # ref:891-893
+
+
+# ----------------------------------------------------------------------------------------------
 # batched driver over the panel+offset layout of include/tangency_posterior.h (numpy loop; small cases)
 def posterior_batch(strategy, k, N, gamma, panel, start, n_r, hf_panel=None, hf_start=None, m=None,
                     w0=None, n0=None, row_idx=None, n_rows=None, col_idx=None, rf_adj=None,
-                    hf_row_idx=None, hf_count=None):
+                    hf_row_idx=None, hf_count=None, rhs=None, center_rows=False):
     """Loop `conjugate_window` / `jeffreys_window` over W windows described the way the C-ABI takes them.
 
     Returns (weights [W x k], status [W] int32, aux [W x 8] = n0, n1, c, q0, q1, denom, 0, 0).
@@ -192,7 +213,7 @@ def posterior_batch(strategy, k, N, gamma, panel, start, n_r, hf_panel=None, hf_
                 if not (denom > 0):
                     status[w] = STATUS_BAD_DENOM
             elif strategy == "jeffreys":
-                wt = jeffreys_window(X, N, gamma)
+                wt = jeffreys_window(X, X.shape[0] if center_rows else N, gamma, rhs=None if rhs is None else rhs[w])
             else:
                 raise ValueError("Unknown weights spec.")
         if not np.all(np.isfinite(wt)):
@@ -237,7 +258,7 @@ def c_num_threads() -> int:
 
 def posterior_batch_c(strategy, k, N, gamma, panel, start, n_r, hf_panel=None, hf_start=None, m=0,
                       w0=None, n0=None, row_idx=None, n_rows=None, col_idx=None, rf_adj=None,
-                      hf_row_idx=None, hf_count=None, threads=0):
+                      hf_row_idx=None, hf_count=None, threads=0, rhs=None, center_rows=False):
     """Same contract as `posterior_batch`, computed by the C restatement (OpenMP over windows)."""
     lib = _lib()
     f64 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
@@ -246,7 +267,7 @@ def posterior_batch_c(strategy, k, N, gamma, panel, start, n_r, hf_panel=None, h
     panel = f64(panel); hf_panel = f64(hf_panel); w0 = f64(w0); n0 = f64(n0); rf_adj = f64(rf_adj)
     start = i64(start); hf_start = i64(hf_start)
     row_idx = i32(row_idx); n_rows = i32(n_rows); col_idx = i32(col_idx)
-    hf_row_idx = i32(hf_row_idx); hf_count = i32(hf_count)
+    hf_row_idx = i32(hf_row_idx); hf_count = i32(hf_count); rhs = f64(rhs)
     W = len(start) if start is not None else row_idx.shape[0]
     weights = np.empty((W, k)); status = np.zeros(W, dtype=np.int32); aux = np.zeros((W, 8))
     strat = {"conjugate": 0, "jeffreys": 1}[strategy]
@@ -260,7 +281,7 @@ def posterior_batch_c(strategy, k, N, gamma, panel, start, n_r, hf_panel=None, h
         _p(hf_start, ctypes.c_longlong), _p(hf_row_idx, ctypes.c_int), _p(hf_count, ctypes.c_int),
         _p(w0, ctypes.c_double), _p(n0, ctypes.c_double),
         _p(weights, ctypes.c_double), _p(status, ctypes.c_int), _p(aux, ctypes.c_double),
-        ctypes.c_int(threads))
+        ctypes.c_int(threads), _p(rhs, ctypes.c_double), ctypes.c_int(1 if center_rows else 0))
     if rc != 0:
         raise RuntimeError(f"oracle_posterior_batch failed rc={rc}")
     return weights, status, aux

@@ -23,7 +23,7 @@ def _spec(strat, size, N, window_freq, rebal):
     simple = strat in ("vw", "ew")
     return {"weighting_strategy": strat, "size": size, "risk_aversion": None if simple else 5, "turnover_cost": 15,
             "rebalancing_frequency": rebal, "rolling_window": N, "rolling_window_frequency": window_freq,
-            "mcm_scaling": None if simple or strat == "jeffreys" else 1, "display_name": strat}
+            "mcm_scaling": None if simple or strat in ("jeffreys", "jorion") else 1, "display_name": strat}
 
 
 @pytest.mark.parametrize("name", ["backtest_k10_n60_daily", "backtest_k8_n30_weekly_monthly",
@@ -95,8 +95,36 @@ def test_helper_functions_match_reference(pc, name):
 def test_out_of_scope_strategies_raise(pc):
     md, _ = synthetic.make_market_data(n_tickers=6, n_days=40, seed=5)
     d = md["stock_prices_df"].index[-1]
-    for strat in ("shrinkage", "black_litterman", "jorion", "greyserman"):
+    for strat in ("shrinkage", "black_litterman", "greyserman"):
         with pytest.raises(NotImplementedError):
             pc.calculate_portfolio_weights(d, _spec(strat, 4, 20, "daily", "daily"), md)
     with pytest.raises(ValueError):
         pc.calculate_portfolio_weights(d, _spec("no_such_strategy", 4, 20, "daily", "daily"), md)
+
+
+def test_jorion_matches_reference(pc):
+    """F3: Jorion's Bayes-Stein portfolio on the device solves vs the reference (single windows)."""
+    g = np.load(os.path.join(GOLDEN, "jorion_single.npz"))
+    for k, N in ((10, 60), (33, 80), (100, 250)):
+        inp = synthetic.make_kernel_inputs(k, N, 2, int(g[f"k{k}_n{N}_seed"]))
+        tickers = [f"A{i:04d}" for i in range(k)]
+        for w in range(2):
+            date, prices_df, intraday_df, caps_df, rf_df = synthetic.window_frames(inp, w, tickers)
+            spec = _spec("jorion", k, N, "daily", "daily")
+            wts = pc.calculate_jorion_portfolio(spec, date, prices_df, rf_df)
+            assert list(wts.index) == tickers and wts.index.name == "Stock"
+            np.testing.assert_allclose(wts["Weight"].to_numpy(), g[f"k{k}_n{N}_w{w}_weights"], rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("name", ["backtest_k10_n60_daily_jorion", "backtest_k8_n30_weekly_monthly_jorion"])
+def test_jorion_backtest_matches_reference(pc, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    md, tickers = synthetic.make_market_data(n_tickers=int(g["n_tickers"]), n_days=int(g["n_days"]),
+                                             seed=int(g["seed"]), rf_nan_every=int(g["rf_nan_every"]))
+    days = md["stock_prices_df"].index
+    spec = _spec("jorion", int(g["size"]), int(g["N"]), str(g["window_freq"]), str(g["rebal"]))
+    res = pc.backtest_portfolio(spec, days[int(g["start_idx"])], days[-1], md)
+    np.testing.assert_allclose(res["portfolio_simple_returns_series"].to_numpy(), g["jorion_returns"], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(res["portfolio_turnover_series"].to_numpy(), g["jorion_turnover"], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(res["portfolio_weights_metrics_df"].to_numpy(), g["jorion_metrics"], rtol=1e-7, atol=1e-10,
+                               equal_nan=True)

@@ -120,3 +120,33 @@ def test_conjugate_prior_n_matches_reference_rule():
     assert oracle.conjugate_prior_n(np.array([10.0, 10.0, 20.0]), 3) == pytest.approx(3 * 20 / (40 / 3))
     assert oracle.conjugate_prior_n(np.array([20.0, 20.0, 10.0]), 3) == pytest.approx(3 * (50 / 3) / 10)
     assert oracle.conjugate_prior_n(np.array([5.0, 7.0, 9.0, 11.0]), 2, 0.5) == pytest.approx(2 * 11 / 10 * 0.5)
+
+
+def test_jorion_oracle_matches_reference():
+    """F3: the Jorion (Bayes-Stein) restatement against the reference's calculate_jorion_portfolio."""
+    g = np.load(os.path.join(GOLDEN, "jorion_single.npz"))
+    for k, N in ((10, 60), (33, 80), (100, 250)):
+        inp = synthetic.make_kernel_inputs(k, N, 2, int(g[f"k{k}_n{N}_seed"]))
+        for w in range(2):
+            x = inp["panel"][w:w + N - 1]
+            P = 100.0 * np.exp(np.concatenate([np.zeros((1, k)), np.cumsum(x, axis=0)]))
+            X = oracle.excess_log_returns_from_prices(P)
+            np.testing.assert_allclose(oracle.jorion_window(X, 5.0), g[f"k{k}_n{N}_w{w}_weights"], rtol=1e-8, atol=1e-11)
+
+
+def test_jorion_host_algebra_matches_oracle():
+    """The product's Sherman-Morrison algebra on top of the two solves, with numpy standing in for
+    the device solves (CPU-only check of portfolio_calculations._jorion_from_solves)."""
+    from incorporating_different_sources_amd import portfolio_calculations as pc
+    rng = np.random.default_rng(5)
+    W, k = 4, 9
+    Ts = np.array([40, 37, 25, 31])
+    xt, xo, tt, ref = [], [], [], []
+    for T in Ts:
+        X = rng.normal(3e-4, 0.01, size=(T, k)) + rng.normal(0, 0.01, size=(T, 1))
+        t = X.sum(axis=0)
+        J = X.T @ X - np.outer(t, t) / T
+        xt.append(np.linalg.solve(J, t)); xo.append(np.linalg.solve(J, np.ones(k))); tt.append(t)
+        ref.append(oracle.jorion_window(X, 5.0))
+    got = pc._jorion_from_solves(np.array(xt), np.array(xo), np.array(tt), Ts, k, 5.0)
+    np.testing.assert_allclose(got, np.array(ref), rtol=1e-9, atol=1e-12)
