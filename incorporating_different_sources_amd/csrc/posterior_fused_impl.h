@@ -373,6 +373,7 @@ __device__ __forceinline__ void gram_phase(const RowSource& src, const int* __re
 #undef TP_LOOPSTAMP
 }
 
+
 template <int NT, int NW, int FIX>
 __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, const int tid0, const int wv) {
     using C = Cfg<NT, NW>;
@@ -617,6 +618,17 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
     }
     }
     if (dbg == 3) dump_matrix();
+#ifdef TP_STAMP
+    if (A.phase_limit == 1) {      // diagnostic build only: time the Gram phases alone (keep the tiles alive)
+        double sink = 0.0;
+        static_for<0, C::SLOTS>([&](auto sc_) __attribute__((always_inline)) {
+            constexpr int s = decltype(sc_)::value;
+            sink += acc[s][0] + acc[s][1] + acc[s][2] + acc[s][3];
+        });
+        if (sink == 123.456) A.weights[w * k] = sink;
+        return;
+    }
+#endif
 
     TP_MARK(4);
     // ---- phase F: blocked upper Cholesky S1 = R'R with the border column riding along.

@@ -34,6 +34,7 @@ struct tp_kargs_t {
     long long w_first, w_count;
     int panel_ld, hf_ld;
     int k, N, n_r, m, strategy;
+    int phase_limit;      // diagnostic (TP_PHASE_LIMIT): 1 = stop after the Gram phases (outputs are then invalid)
     int center_rows;      // Jeffreys: divide t t' by the window's row count instead of N
     double gamma;
 };

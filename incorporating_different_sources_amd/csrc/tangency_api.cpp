@@ -128,6 +128,10 @@ tp_kargs_t make_kargs(tp_batch_t b) {
     a.n0 = (const double*)b->n0.p;
     a.rhs = (const double*)b->rhs.p;
     a.center_rows = (b->p.flags & TP_FLAG_CENTER_BY_ROWS) ? 1 : 0;
+    a.phase_limit = 0;
+#ifdef TP_STAMP
+    { const char* pl = getenv("TP_PHASE_LIMIT"); a.phase_limit = pl ? atoi(pl) : 0; }   // diagnostic build only
+#endif
     a.weights = (double*)b->weights.p;
     a.status = (int*)b->status.p;
     a.aux = (double*)b->aux.p;
