@@ -56,6 +56,8 @@ extern "C" {
 /* tp_params_t.flags */
 #define TP_FLAG_CENTER_BY_ROWS 1 /* Jeffreys scatter T - t t'/n_w with n_w = the rows window w actually
                                    uses instead of N: (n_w - 1) x the sample covariance (ref:876, 917) */
+#define TP_FLAG_NO_CENTER 2      /* Jeffreys strategy on the plain Gram matrix T = X'X (no - t t'/N term):
+                                   (n-1) S + n xbar xbar' of ref:924 is exactly T */
 
 typedef struct tp_handle_s* tp_handle_t;
 typedef struct tp_batch_s* tp_batch_t;
@@ -120,10 +122,15 @@ int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in);   /* H2D, synchronous 
  * conjugate posterior) in every later tp_batch_run: the weights become (matrix)^-1 rhs / gamma.  NULL
  * restores the default.  Binds the V^-1 1 / V^-1 mu solves of calculate_jorion_portfolio (ref:880-891). */
 int tp_batch_set_rhs(tp_batch_t b, const double* rhs);
+/* Optional per-window shift [W x 2] = (d_w, e_w), Jeffreys strategy only: the matrix that is factorised
+ * becomes J_w + d_w I + e_w 1 1' in every later tp_batch_run (NULL restores the default).  d_w >= 0,
+ * e_w >= 0 keep it positive definite.  Binds the scale matrix D_h of calculate_greyserman_portfolio
+ * (ref:924: eta_b S_h = eta_b/2 (I + 1 1'), kappa_h xi_b^2 1 1'), one window per posterior draw. */
+int tp_batch_set_shift(tp_batch_t b, const double* shift);
 int tp_batch_run(tp_batch_t b);                             /* async on the handle's stream; HIP-event timed */
 /* The right-hand side each window was solved for in the last run (default: t = X'1, ref:222, resp.
  * c S0 w0 + t, ref:489); runs the batch once if it has not kept it yet. */
-int tp_batch_download_rhs(tp_batch_t b, double* rhs_out /* [W x k] */);                             /* async on the handle's stream; HIP-event timed */
+int tp_batch_download_rhs(tp_batch_t b, double* rhs_out /* [W x k] */);
 int tp_batch_download(tp_batch_t b, double* weights /* [W x k] */, int32_t* status /* [W] */,
                       double* aux /* optional [W x TP_AUX_STRIDE] */); /* waits for the stream, D2H */
 int tp_batch_download_S1(tp_batch_t b, int64_t w, double* S1 /* [k x k] */); /* posterior scale matrix

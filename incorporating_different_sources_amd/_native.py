@@ -26,12 +26,13 @@ STRATEGY_JEFFREYS = 1
 STATUS_OK, STATUS_NOT_PD, STATUS_NONFINITE, STATUS_BAD_DENOM = 0, 1, 2, 3
 AUX_STRIDE = 8
 FLAG_CENTER_BY_ROWS = 1
+FLAG_NO_CENTER = 2
 UNIQUE_ID_BYTES = 128
 
 # every symbol include/tangency_posterior.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTS = [
     "tp_version", "tp_max_assets", "tp_device_count", "tp_create", "tp_destroy", "tp_last_error", "tp_device_info",
-    "tp_batch_create", "tp_batch_upload", "tp_batch_set_rhs", "tp_batch_download_rhs", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1", "tp_batch_download_matrix", "tp_batch_debug_stamps",
+    "tp_batch_create", "tp_batch_upload", "tp_batch_set_rhs", "tp_batch_set_shift", "tp_batch_download_rhs", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1", "tp_batch_download_matrix", "tp_batch_debug_stamps",
     "tp_batch_destroy", "tp_posterior_batch", "tp_synchronize", "tp_last_timing", "tp_region_begin",
     "tp_region_end", "tp_last_launch", "tp_comm_unique_id", "tp_comm_init", "tp_comm_destroy",
     "tp_batch_gather", "tp_batch_download_gathered",
@@ -74,6 +75,7 @@ def _load():
     lib.tp_batch_create.argtypes = [c_void_p, POINTER(tp_params_t), c_int64, POINTER(c_void_p)]
     lib.tp_batch_upload.argtypes = [c_void_p, POINTER(tp_inputs_t)]
     lib.tp_batch_set_rhs.argtypes = [c_void_p, POINTER(c_double)]
+    lib.tp_batch_set_shift.argtypes = [c_void_p, POINTER(c_double)]
     lib.tp_batch_download_rhs.argtypes = [c_void_p, POINTER(c_double)]
     lib.tp_batch_run.argtypes = [c_void_p]
     lib.tp_batch_download.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int32), POINTER(c_double)]
@@ -264,6 +266,12 @@ class Batch:
         self.dev._check(lib.tp_batch_set_rhs(self._b, _ptr(r, c_double)))
         return self
 
+    def set_shift(self, shift):
+        """Per-window (d, e) [W x 2]: the Jeffreys matrix becomes J + d I + e 1 1' (None: no shift)."""
+        sh = _arr(shift, np.float64, (self.W, 2), "shift")
+        self.dev._check(lib.tp_batch_set_shift(self._b, _ptr(sh, c_double)))
+        return self
+
     def download_rhs(self) -> np.ndarray:
         """[W x k] right-hand sides the windows were solved for (t = X'1 by default)."""
         out = np.empty((self.W, self.k), dtype=np.float64)
@@ -336,7 +344,8 @@ def default_device() -> Device:
 
 def posterior_batch(strategy, k, N, gamma, panel, start=None, n_r=None, hf_panel=None, hf_start=None, m=0,
                     w0=None, n0=None, row_idx=None, n_rows=None, col_idx=None, rf_adj=None,
-                    hf_row_idx=None, hf_count=None, device: Device | None = None, want_aux=True, rhs=None, flags=0):
+                    hf_row_idx=None, hf_count=None, device: Device | None = None, want_aux=True, rhs=None, flags=0,
+                    shift=None):
     """Upload + run + download.  Same argument meaning as `oracle.posterior_batch` (tests compare them)."""
     dev = device or default_device()
     W = len(start) if start is not None else len(row_idx)
@@ -344,6 +353,8 @@ def posterior_batch(strategy, k, N, gamma, panel, start=None, n_r=None, hf_panel
     try:
         if rhs is not None:
             b.set_rhs(rhs)
+        if shift is not None:
+            b.set_shift(shift)
         b.upload(panel, start=start, hf_panel=hf_panel, hf_start=hf_start, w0=w0, n0=n0, row_idx=row_idx,
                  n_rows=n_rows, col_idx=col_idx, rf_adj=rf_adj, hf_row_idx=hf_row_idx, hf_count=hf_count)
         b.run()

@@ -564,7 +564,12 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
     if (!conj) {
         // ---- phase E: J = T - t t'/N (ref:600-601); t stays in the border column (ref:606 rhs)
         __syncthreads();
-        const double invN = 1.0 / (double)(A.center_rows ? (A.n_rows ? A.n_rows[w] : A.n_r) : A.N);
+        // center_rows 2 (TP_FLAG_NO_CENTER): the plain Gram matrix; shift (d, e): + d I + e 1 1' on the k x k
+        // block (tp_batch_set_shift) - ridge / equicorrelated prior scale matrices such as ref:917, 924
+        const double invN = A.center_rows == 2 ? 0.0
+                          : 1.0 / (double)(A.center_rows ? (A.n_rows ? A.n_rows[w] : A.n_r) : A.N);
+        const double sh_d = A.shift ? A.shift[2 * w] : 0.0;
+        const double sh_e = A.shift ? A.shift[2 * w + 1] : 0.0;
         wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
             for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
                 constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
@@ -573,7 +578,8 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
                 for (int r = 0; r < 4; ++r) {
                     const double ti = lds[C::OFF_YBAR + 16 * I + fq + 4 * r];
                     const bool on = (J < kI || colv) && (I < kI || fq + 4 * r < kc);
-                    acc[s][r] -= on ? invN * (ti * tj) : 0.0;
+                    const double add = sh_e + ((I == J && fq + 4 * r == fr) ? sh_d : 0.0);
+                    acc[s][r] += on ? add - invN * (ti * tj) : 0.0;
                 }
             });
         });

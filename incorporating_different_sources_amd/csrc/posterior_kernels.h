@@ -23,6 +23,7 @@ struct tp_kargs_t {
     const double* w0;
     const double* n0;
     const double* rhs;    // optional [W x k]: replaces the border column before the factorisation
+    const double* shift;  // optional [W x 2], Jeffreys only: (d, e) adds d I + e 1 1' to the matrix that is factorised
     double* weights;
     int* status;
     double* aux;
@@ -35,7 +36,7 @@ struct tp_kargs_t {
     int panel_ld, hf_ld;
     int k, N, n_r, m, strategy;
     int phase_limit;      // diagnostic (TP_PHASE_LIMIT): 1 = stop after the Gram phases (outputs are then invalid)
-    int center_rows;      // Jeffreys: divide t t' by the window's row count instead of N
+    int center_rows;      // Jeffreys: 0 = J = T - t t'/N, 1 = divide by the window's row count instead, 2 = plain T
     double gamma;
 };
 

@@ -283,12 +283,15 @@ __global__ void __launch_bounds__(NTHREADS) tiled_rank1_kernel(const tp_kargs_t 
     int SI, SJ;
     pair_decode(blockIdx.y, NS, SI, SJ);
     const long long w = A.w_first + wl;
-    const double invN = 1.0 / (double)(A.center_rows ? (A.n_rows ? A.n_rows[w] : A.n_r) : A.N);
+    const double invN = A.center_rows == 2 ? 0.0
+                      : 1.0 / (double)(A.center_rows ? (A.n_rows ? A.n_rows[w] : A.n_r) : A.N);
+    const double sh_d = A.shift ? A.shift[2 * w] : 0.0;         // tp_batch_set_shift: + d I + e 1 1'
+    const double sh_e = A.shift ? A.shift[2 * w + 1] : 0.0;
     for (int e = tid; e < SB * SB; e += NTHREADS) {
         const int gi = 64 * SI + (e >> 6), gj = 64 * SJ + (e & 63);
         if (gi < k && gj < k) {
             const double ti = M[(long long)gi * KP + k], tj = M[(long long)gj * KP + k];
-            M[(long long)gi * KP + gj] -= invN * (ti * tj);
+            M[(long long)gi * KP + gj] += sh_e + (gi == gj ? sh_d : 0.0) - invN * (ti * tj);
         }
     }
 }

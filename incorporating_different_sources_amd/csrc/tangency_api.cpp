@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -46,7 +47,7 @@ struct tp_batch_s {
     int64_t W = 0;
     int panel_ld = 0, hf_ld = 0;
     DevBuf panel, start, row_idx, n_rows, col_idx, rf_adj, hf_panel, hf_start, hf_row_idx, hf_count, w0, n0;
-    DevBuf weights, status, aux, dbg, gather_w, gather_s, stamps, rhs, out_rhs;
+    DevBuf weights, status, aux, dbg, gather_w, gather_s, stamps, rhs, out_rhs, shift;
     DevBuf t_arena, t_rinv, t_ybar, t_zc, t_scal, t_flags;   // large-k path workspace
     int64_t tiled_capacity = 0;                               // windows in flight per sub-batch
     bool uploaded = false;
@@ -127,7 +128,8 @@ tp_kargs_t make_kargs(tp_batch_t b) {
     a.w0 = (const double*)b->w0.p;
     a.n0 = (const double*)b->n0.p;
     a.rhs = (const double*)b->rhs.p;
-    a.center_rows = (b->p.flags & TP_FLAG_CENTER_BY_ROWS) ? 1 : 0;
+    a.shift = (const double*)b->shift.p;
+    a.center_rows = (b->p.flags & TP_FLAG_NO_CENTER) ? 2 : (b->p.flags & TP_FLAG_CENTER_BY_ROWS) ? 1 : 0;
     a.phase_limit = 0;
 #ifdef TP_STAMP
     { const char* pl = getenv("TP_PHASE_LIMIT"); a.phase_limit = pl ? atoi(pl) : 0; }   // diagnostic build only
@@ -352,7 +354,7 @@ int tp_batch_destroy(tp_batch_t b) {
     (void)hipStreamSynchronize(b->h->stream);
     DevBuf* all[] = {&b->panel, &b->start, &b->row_idx, &b->n_rows, &b->col_idx, &b->rf_adj, &b->hf_panel, &b->hf_start,
                      &b->hf_row_idx, &b->hf_count, &b->w0, &b->n0, &b->weights, &b->status, &b->aux, &b->dbg,
-                     &b->gather_w, &b->gather_s, &b->stamps, &b->rhs, &b->out_rhs, &b->t_arena, &b->t_rinv, &b->t_ybar, &b->t_zc,
+                     &b->gather_w, &b->gather_s, &b->stamps, &b->rhs, &b->out_rhs, &b->shift, &b->t_arena, &b->t_rinv, &b->t_ybar, &b->t_zc,
                      &b->t_scal, &b->t_flags};
     for (DevBuf* d : all) release(*d);
     delete b;
@@ -403,6 +405,23 @@ int tp_batch_set_rhs(tp_batch_t b, const double* rhs) {
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));       // a running launch may still read the old one
     int rc = put(h, b->rhs, rhs, sizeof(double) * (size_t)b->W * b->p.k);
+    if (rc != TP_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return TP_OK;
+}
+
+int tp_batch_set_shift(tp_batch_t b, const double* shift) {
+    if (!b) return TP_ERR_INVALID;
+    tp_handle_t h = b->h;
+    if (shift && b->p.strategy != TP_STRATEGY_JEFFREYS)
+        return fail(h, TP_ERR_INVALID, "tp_batch_set_shift applies to the Jeffreys strategy only");
+    if (shift)
+        for (int64_t i = 0; i < 2 * b->W; ++i)
+            if (!(shift[i] >= 0.0) || !std::isfinite(shift[i]))
+                return fail(h, TP_ERR_INVALID, "tp_batch_set_shift: shift[%lld] must be finite and >= 0", (long long)i);
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));       // a running launch may still read the old one
+    int rc = put(h, b->shift, shift, sizeof(double) * 2 * (size_t)b->W);
     if (rc != TP_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return TP_OK;

@@ -15,8 +15,10 @@ pandas:
 There is no CPU fallback for the estimators: without `libtangency.so` and a gfx950 GPU they raise.
 The passive weightings (vw / ew, ref:661-701) are host-side, as they are inputs (prior weights w0 and
 the comparison portfolio), not part of the accelerated path.  Jorion's Bayes-Stein portfolio (ref:851-895)
-reuses the device's scatter + Cholesky solve with two right-hand sides.  Shrinkage, Black-Litterman and
-Greyserman (ref:703-817, 897-938) are outside the scope of this build and raise NotImplementedError.
+reuses the device's scatter + Cholesky solve with two right-hand sides, and so does the Greyserman
+hierarchical prior (ref:897-938), one ridge-shifted window per hyper-parameter draw.  Shrinkage and
+Black-Litterman (ref:703-817: pypfopt, not in the tree) are outside the scope of this build and raise
+NotImplementedError.
 """
 from __future__ import annotations
 
@@ -43,7 +45,7 @@ logger = logging.getLogger(__name__)
 CHECK = False
 
 _CONJUGATE = ("conjugate_hf_vix_vw", "conjugate_hf_vix_ew", "conjugate_hf_epu_vw", "conjugate_hf_epu_ew")
-_OUT_OF_SCOPE = ("shrinkage", "black_litterman", "greyserman")
+_OUT_OF_SCOPE = ("shrinkage", "black_litterman")
 _RESAMPLE_RULE = {"weekly": "W", "monthly": "ME"}
 
 
@@ -453,7 +455,6 @@ def _not_in_scope(name):
 
 calculate_shrinkage_portfolio = _not_in_scope("calculate_shrinkage_portfolio")
 calculate_black_litterman_portfolio = _not_in_scope("calculate_black_litterman_portfolio")
-calculate_greyserman_portfolio = _not_in_scope("calculate_greyserman_portfolio")
 
 
 def _jorion_from_solves(x_t, x_one, t, T, N, gamma):
@@ -506,6 +507,101 @@ def calculate_jorion_portfolio(portfolio_spec, trading_date_ts, k_stock_prices_d
     kw = dict(panel=X, start=np.zeros(1, np.int64), n_r=X.shape[0], n_rows=np.array([X.shape[0]], np.int32),
               rf_adj=rf_rows[None, :])
     w = _jorion_batch(kw, portfolio_spec["risk_aversion"], k, portfolio_spec["rolling_window"])
+    return pd.DataFrame({"Weight": w[0]}, index=pd.Index(labels, name="Stock"))
+
+
+# ------------------------------------------------------------------------------------------------------
+# Greyserman et al. hierarchical prior (ref:897-938): a Monte-Carlo mean over hyper-parameter draws, every
+# draw one SPD system D_h x = a_h of the window's size - a batched-Cholesky workload for the device.
+GREYSERMAN_DRAWS = 1000            # ref:925
+_GREYSERMAN_DATES_PER_LAUNCH = 32  # dates x draws windows per device batch (index arrays are repeated per draw)
+
+
+def _greyserman_draws(count):
+    """(xi_b, eta_b) in the reference's order from numpy's global generator (ref:926-927), so that
+    `numpy.random.seed` reproduces the reference's weights.  scipy's `gamma.rvs(a=1, scale=10)` is
+    `standard_gamma(1) * 10` on that same generator."""
+    xi = np.empty(count)
+    eta = np.empty(count)
+    for i in range(count):
+        xi[i] = np.random.uniform(-1000, 1000)
+        eta[i] = np.random.standard_gamma(1.0) * 10
+    return xi, eta
+
+
+def _greyserman_from_solves(u_t, u_one, t, n, xi, eta, k, gamma):
+    """Mean over draws of the weights of ref:928-931 from two device solves per draw with the ridge matrix
+    B_b = T + (eta_b/2) I:  u_t = B_b^-1 t and u_one = B_b^-1 1  (T = X'X is (n-1) S + n xbar xbar' of ref:929).
+
+    With g = n + kappa, beta = eta_b/2 + kappa xi_b^2 and a_h = (t + kappa xi_b 1)/g the scale matrix of ref:929
+    is D_h = B_b + beta 1 1' - g a_h a_h' = B_b + U C U' with U = [1, t].  Woodbury over that rank-two term,
+    K = C^-1 + U' B_b^-1 U, collapses (C^-1 [kappa xi_b, 1]'/g = -e_2) to
+        D_h^-1 a_h = (K12 u_one - K11 u_t) / det K,
+        K11 = 1/beta + 1'u_one,  K12 = 1'u_t - kappa xi_b/beta,  K22 = t'u_t - n - kappa eta_b/(2 beta),
+    in which no two large terms cancel (det K is a sum of two negative terms) - unlike the LU inverse of
+    D_h itself, whose condition number reaches 1e10.  Shapes: u_t, u_one [W x B x k]; t [W x k]; n [W];
+    xi, eta [W x B]."""
+    n = np.asarray(n, dtype=np.float64)[:, None]
+    kappa = np.array([round(0.1 * v) for v in n[:, 0]], dtype=np.float64)[:, None]       # ref:920
+    beta = eta / 2 + kappa * xi ** 2
+    K11 = 1 / beta + u_one.sum(axis=2)
+    K12 = u_t.sum(axis=2) - kappa * xi / beta
+    K22 = (u_t * t[:, None, :]).sum(axis=2) - n - kappa * eta / (2 * beta)
+    det = K11 * K22 - K12 ** 2
+    x = (K12 / det)[:, :, None] * u_one - (K11 / det)[:, :, None] * u_t                  # D_h^-1 a_h
+    nu_h = k                                                                             # ref:921
+    scale = 1 / gamma * (nu_h + n + 1) * (1 - 1 / (nu_h + n - k))                        # ref:931
+    return (scale[:, :, None] * x).mean(axis=1)
+
+
+def _greyserman_batch(kw, gamma, k, N, draws=None):
+    """All dates of `kw` (the `batch.pack_windows` layout), GREYSERMAN_DRAWS windows per date."""
+    dev = _native.default_device()
+    n_rows = np.asarray(kw["n_rows"])
+    W = len(n_rows)
+    B = GREYSERMAN_DRAWS if draws is None else np.asarray(draws[0]).shape[-1]
+    if draws is None:
+        pairs = [_greyserman_draws(B) for _ in range(W)]          # date-major, as the reference's day loop draws
+        xi = np.array([p[0] for p in pairs])
+        eta = np.array([p[1] for p in pairs])
+    else:
+        xi = np.broadcast_to(np.asarray(draws[0], dtype=np.float64), (W, B))
+        eta = np.broadcast_to(np.asarray(draws[1], dtype=np.float64), (W, B))
+    per_window = ("start", "row_idx", "n_rows", "col_idx", "rf_adj")
+    out = np.empty((W, k))
+    for lo in range(0, W, _GREYSERMAN_DATES_PER_LAUNCH):
+        hi = min(W, lo + _GREYSERMAN_DATES_PER_LAUNCH)
+        sub = {key: (np.repeat(np.asarray(val)[lo:hi], B, axis=0) if key in per_window and val is not None else val)
+               for key, val in kw.items() if key not in ("n_r", "m")}
+        Wb = (hi - lo) * B
+        shift = np.zeros((Wb, 2))
+        shift[:, 0] = eta[lo:hi].reshape(-1) / 2                                         # eta_b S_h = eta_b/2 (I + 11')
+        b = _native.Batch(dev, "jeffreys", k, N, kw["n_r"], 1.0, Wb, 0, flags=_native.FLAG_NO_CENTER)
+        try:
+            b.set_shift(shift)
+            b.upload(**sub)
+            t = b.download_rhs()
+            u_t, status, _ = b.run().download(want_aux=False)
+            _raise_on_status(status)
+            b.set_rhs(np.ones((Wb, k)))
+            u_one, status, _ = b.run().download(want_aux=False)
+            _raise_on_status(status)
+        finally:
+            b.close()
+        out[lo:hi] = _greyserman_from_solves(u_t.reshape(hi - lo, B, k), u_one.reshape(hi - lo, B, k),
+                                             t.reshape(hi - lo, B, k)[:, 0, :], n_rows[lo:hi], xi[lo:hi], eta[lo:hi],
+                                             k, gamma)
+    return out
+
+
+def calculate_greyserman_portfolio(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df, draws=None):
+    """Greyserman portfolio (ref:897-938): 2 x 1000 ridge solves on the device, rank-two algebra on the host.
+    `draws=(xi, eta)` replaces the random hyper-parameter draws (testing)."""
+    X, rf_rows, labels = _daily_window_arrays(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df)
+    k = len(labels)
+    kw = dict(panel=X, start=np.zeros(1, np.int64), n_r=X.shape[0], n_rows=np.array([X.shape[0]], np.int32),
+              rf_adj=rf_rows[None, :])
+    w = _greyserman_batch(kw, portfolio_spec["risk_aversion"], k, portfolio_spec["rolling_window"], draws=draws)
     return pd.DataFrame({"Weight": w[0]}, index=pd.Index(labels, name="Stock"))
 
 
@@ -608,7 +704,7 @@ def calculate_portfolio_weights_batch(trading_dates, portfolio_spec, market_data
         return [calculate_portfolio_weights(d, portfolio_spec, market_data) for d in trading_dates]
     if strategy in _OUT_OF_SCOPE:
         _not_in_scope(f"calculate_{strategy}_portfolio")()
-    if strategy not in _CONJUGATE and strategy not in ("jeffreys", "jorion"):
+    if strategy not in _CONJUGATE and strategy not in ("jeffreys", "jorion", "greyserman"):
         logger.error("Unknown weights spec.")
         raise ValueError("Unknown weights spec.")
     if not trading_dates:
@@ -618,6 +714,9 @@ def calculate_portfolio_weights_batch(trading_dates, portfolio_spec, market_data
     if strategy == "jorion":
         kw.pop("start", None)
         weights = _jorion_batch(kw, portfolio_spec["risk_aversion"], portfolio_spec["size"], portfolio_spec["rolling_window"])
+        return [pd.DataFrame({"Weight": weights[i]}, index=pd.Index(labels[i], name="Stock")) for i in range(len(labels))]
+    if strategy == "greyserman":
+        weights = _greyserman_batch(kw, portfolio_spec["risk_aversion"], portfolio_spec["size"], portfolio_spec["rolling_window"])
         return [pd.DataFrame({"Weight": weights[i]}, index=pd.Index(labels[i], name="Stock")) for i in range(len(labels))]
     conj = strategy in _CONJUGATE
     weights, status, aux = _native.posterior_batch("conjugate" if conj else "jeffreys", portfolio_spec["size"],
@@ -777,7 +876,7 @@ def backtest_portfolio(portfolio_spec, ts_start_date, ts_end_date, market_data):
     trading_dates = [ts for ts in trading_dates if ts_start_date <= ts <= ts_end_date]
     strategy = portfolio_spec["weighting_strategy"]
     precomputed = {}
-    if strategy in _CONJUGATE or strategy in ("jeffreys", "jorion"):
+    if strategy in _CONJUGATE or strategy in ("jeffreys", "jorion", "greyserman"):
         rebalance_dates = rebalancing_schedule(trading_dates, portfolio_spec["rebalancing_frequency"])
         frames = calculate_portfolio_weights_batch(rebalance_dates, portfolio_spec, market_data)
         precomputed = dict(zip(rebalance_dates, frames))

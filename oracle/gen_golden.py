@@ -117,7 +117,7 @@ def gen_single_windows(pc, name, k, N, hf_days, W, seed, strategies, store_input
 
 
 def gen_backtest(pc, holder, name, strategies, size, N, window_freq, rebal, n_days, n_tickers, seed,
-                 start_idx, rf_nan_every=0):
+                 start_idx, rf_nan_every=0, np_seed=None):
     md, tickers = synthetic.make_market_data(n_tickers=n_tickers, n_days=n_days, seed=seed,
                                              rf_nan_every=rf_nan_every)
     holder["tickers"] = tickers
@@ -133,6 +133,9 @@ def gen_backtest(pc, holder, name, strategies, size, N, window_freq, rebal, n_da
                 "turnover_cost": 15, "rebalancing_frequency": rebal, "rolling_window": N,
                 "rolling_window_frequency": window_freq, "mcm_scaling": None if simple or strat == "jeffreys" else 1,
                 "display_name": strat}
+        if np_seed is not None:             # strategies that draw from numpy's global generator (ref:926-927)
+            np.random.seed(np_seed)
+            out["np_seed"] = np_seed
         res = pc.backtest_portfolio(spec, ts_start, ts_end, md)
         r = res["portfolio_simple_returns_series"]
         t = res["portfolio_turnover_series"]
@@ -146,6 +149,8 @@ def gen_backtest(pc, holder, name, strategies, size, N, window_freq, rebal, n_da
         out[f"{strat}_metrics_cols"] = np.array(list(mdf.columns))
         # per-rebalance weights straight from the dispatch function (ref:941)
         wl, tl = [], []
+        if np_seed is not None:             # same draw sequence as the backtest above: dates in the same order
+            np.random.seed(np_seed)
         for d in mdf.index:
             wdf = pc.calculate_portfolio_weights(d, spec, md)
             wl.append(wdf["Weight"].to_numpy())
@@ -162,7 +167,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     holder = {"tickers": []}
     pc, ps = import_reference(holder)
-    which = sys.argv[1:] or ["single", "backtest", "specs", "large", "jorion"]
+    which = sys.argv[1:] or ["single", "backtest", "specs", "large", "jorion", "greyserman"]
     conj = ["conjugate_hf_vix_vw", "conjugate_hf_vix_ew"]
     if "single" in which:
         # BASELINE config 1 shapes (k=10, N=60), 4 windows, all intermediates + inputs stored
@@ -209,6 +214,30 @@ def main():
                      20240001, 65)
         gen_backtest(pc, holder, "backtest_k8_n30_weekly_monthly_jorion", ["jorion"], 8, 30, "weekly", "monthly",
                      260, 12, 20240011, 170, rf_nan_every=17)
+    if "greyserman" in which:
+        # F3: Greyserman et al. hierarchical prior, 1000 hyper-parameter draws per window (ref:897-938).  The
+        # reference draws from numpy's global generator: seed it, and keep the draws next to the weights.
+        from oracle import oracle as orc
+        out = {}
+        for k, N, seed in ((10, 60, 20240001), (33, 80, 20240033), (100, 250, 20240002)):
+            inp = synthetic.make_kernel_inputs(k, N, 2, seed)
+            tickers = [f"A{i:04d}" for i in range(k)]
+            for w in range(2):
+                date, prices_df, intraday_df, caps_df, rf_df = window_frames(inp, w, tickers)
+                spec = {"weighting_strategy": "greyserman", "size": k, "risk_aversion": 5, "rolling_window": N,
+                        "rolling_window_frequency": "daily", "rebalancing_frequency": "daily"}
+                np.random.seed(seed + w)
+                wts = pc.calculate_greyserman_portfolio(spec, date, prices_df, rf_df)
+                out[f"k{k}_n{N}_w{w}_weights"] = wts["Weight"].to_numpy()
+                np.random.seed(seed + w)
+                xi, eta = orc.greyserman_draws(1000)
+                out[f"k{k}_n{N}_w{w}_xi"] = xi
+                out[f"k{k}_n{N}_w{w}_eta"] = eta
+            out[f"k{k}_n{N}_seed"] = seed
+        np.savez_compressed(os.path.join(OUT, "greyserman_single.npz"), **out)
+        print("wrote greyserman_single.npz")
+        gen_backtest(pc, holder, "backtest_k10_n60_daily_greyserman", ["greyserman"], 10, 60, "daily", "daily", 85, 14,
+                     20240001, 65, np_seed=20240077)
     if "specs" in which:
         specs = ps.create_portfolio_specs()
         keys = list(specs.keys())

@@ -139,19 +139,22 @@ def conjugate_window(X, Y, w0, n0, N, k, gamma, return_aux=False):
 
 # ----------------------------------------------------------------------------------------------
 # Jeffreys posterior (ref:580-608, 838-849)
-def mean_jeffreys_posterior_nu(X: np.ndarray, N: int, rhs=None) -> np.ndarray:
+def mean_jeffreys_posterior_nu(X: np.ndarray, N: int, rhs=None, shift=None) -> np.ndarray:
     """ref:600-606  J = T - (1/N) t t' ;  nu = inv(J) . t   (N = rolling_window, not n_r: Appendix B-Q1).
-    `rhs` replaces t (the C-ABI's tp_batch_set_rhs)."""
+    `rhs` replaces t (the C-ABI's tp_batch_set_rhs); N = None drops the t t'/N term (TP_FLAG_NO_CENTER);
+    `shift` = (d, e) adds d I + e 1 1' (tp_batch_set_shift)."""
     T = canonical_statistics_T(X)
     t = canonical_statistics_t(X)
-    J = T - 1 / N * np.outer(t, t)
+    J = T - 1 / N * np.outer(t, t) if N is not None else T.copy()
+    if shift is not None:
+        J = J + shift[0] * np.eye(J.shape[0]) + shift[1] * np.ones_like(J)
     return np.linalg.inv(J) @ (t if rhs is None else rhs)
 
 
-def jeffreys_window(X, N, gamma, return_aux=False, rhs=None):
+def jeffreys_window(X, N, gamma, return_aux=False, rhs=None, shift=None):
     """ref:838-849 (calculate_jeffreys_portfolio): weights = nu / gamma."""
     X = np.asarray(X, dtype=np.float64)
-    nu = mean_jeffreys_posterior_nu(X, N, rhs)
+    nu = mean_jeffreys_posterior_nu(X, N, rhs, shift)
     weights = 1 / gamma * nu
     if return_aux:
         T = canonical_statistics_T(X)
@@ -181,10 +184,43 @@ def jorion_window(X, gamma):
 
 
 # ----------------------------------------------------------------------------------------------
+# Greyserman et al. hierarchical prior, Monte-Carlo mean over hyper-parameter draws (ref:897-938)
+def greyserman_draws(count=1000):
+    """The reference's draw sequence (ref:925-927): alternating numpy-global uniform(-1000, 1000) and
+    scipy gamma(a=1, scale=10) variates.  Seed with numpy.random.seed for reproducible weights."""
+    from scipy.stats import gamma as _gamma
+    xi = np.empty(count)
+    eta = np.empty(count)
+    for i in range(count):
+        xi[i] = np.random.uniform(-1000, 1000)
+        eta[i] = _gamma.rvs(a=1, scale=10)
+    return xi, eta
+
+
+def greyserman_window(X, gamma, xi, eta):
+    """ref:914-934 for one window of excess log-returns X [n x k] and given draws (xi_b, eta_b)."""
+    X = np.asarray(X, dtype=np.float64)
+    n, k = X.shape
+    x_bar = X.mean(axis=0)[:, None]
+    S = np.cov(X, rowvar=False, ddof=1).reshape(k, k)
+    S_h = np.where(np.eye(k) == 1, 1, 0.5)
+    one = np.ones((k, 1))
+    kappa_h = round(0.1 * n)
+    nu_h = k
+    acc = np.zeros((k, 1))
+    for xi_b, eta_b in zip(xi, eta):
+        a_h = 1 / (n + kappa_h) * (n * x_bar + kappa_h * xi_b * one)
+        D_h = ((n - 1) * S + eta_b * S_h + n * x_bar @ x_bar.T + kappa_h * xi_b ** 2 * one @ one.T
+               - (n + kappa_h) * a_h @ a_h.T)
+        acc += 1 / gamma * (nu_h + n + 1) * (1 - 1 / (nu_h + n - k)) * (np.linalg.inv(D_h) @ a_h)
+    return (acc / len(xi))[:, 0]
+
+
+# ----------------------------------------------------------------------------------------------
 # batched driver over the panel+offset layout of include/tangency_posterior.h (numpy loop; small cases)
 def posterior_batch(strategy, k, N, gamma, panel, start, n_r, hf_panel=None, hf_start=None, m=None,
                     w0=None, n0=None, row_idx=None, n_rows=None, col_idx=None, rf_adj=None,
-                    hf_row_idx=None, hf_count=None, rhs=None, center_rows=False):
+                    hf_row_idx=None, hf_count=None, rhs=None, center_rows=False, no_center=False, shift=None):
     """Loop `conjugate_window` / `jeffreys_window` over W windows described the way the C-ABI takes them.
 
     Returns (weights [W x k], status [W] int32, aux [W x 8] = n0, n1, c, q0, q1, denom, 0, 0).
@@ -213,7 +249,8 @@ def posterior_batch(strategy, k, N, gamma, panel, start, n_r, hf_panel=None, hf_
                 if not (denom > 0):
                     status[w] = STATUS_BAD_DENOM
             elif strategy == "jeffreys":
-                wt = jeffreys_window(X, X.shape[0] if center_rows else N, gamma, rhs=None if rhs is None else rhs[w])
+                wt = jeffreys_window(X, None if no_center else (X.shape[0] if center_rows else N), gamma,
+                                     rhs=None if rhs is None else rhs[w], shift=None if shift is None else shift[w])
             else:
                 raise ValueError("Unknown weights spec.")
         if not np.all(np.isfinite(wt)):

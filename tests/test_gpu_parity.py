@@ -208,3 +208,40 @@ def test_tiled_path_matches_oracle(native, k, N, hf_days, strat):
     np.testing.assert_allclose(wts, ref, rtol=1e-7, atol=1e-10 * scale)
     if strat == "conjugate":
         np.testing.assert_allclose(aux[:, :6], raux[:, :6], rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize("k,N", [(3, 12), (10, 60), (33, 80), (100, 250), (239, 300), (300, 400)])
+def test_shift_and_plain_gram_match_oracle(native, k, N):
+    """tp_batch_set_shift / TP_FLAG_NO_CENTER (the Greyserman scale matrix, ref:924): (T + d I + e 1 1')^-1 rhs
+    and (T - t t'/N + d I + e 1 1')^-1 t on both the fused (k <= 239) and the tiled path."""
+    W = 4
+    inp = synthetic.make_kernel_inputs(k, N, W, seed=770000 + k)
+    rng = np.random.default_rng(k)
+    shift = np.column_stack([rng.gamma(1.0, 10.0, W) / 2, rng.uniform(0, 50.0, W)])
+    shift[0] = (0.0, 0.0)
+    rhs = rng.normal(size=(W, k))
+    kw = dict(panel=inp["panel"], start=inp["start"], n_r=inp["n_r"])
+    # plain Gram + shift, caller's right-hand side
+    ref, rstat, _ = oracle.posterior_batch("jeffreys", k, N, 1.0, **kw, rhs=rhs, shift=shift, no_center=True)
+    got, status, _ = native.posterior_batch("jeffreys", k, N, 1.0, **kw, rhs=rhs, shift=shift,
+                                            flags=native.FLAG_NO_CENTER)
+    assert (status == 0).all()
+    np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(ref).max()))
+    # Jeffreys scatter + shift, default right-hand side t
+    ref, rstat, _ = oracle.posterior_batch("jeffreys", k, N, 5.0, **kw, shift=shift)
+    got, status, _ = native.posterior_batch("jeffreys", k, N, 5.0, **kw, shift=shift)
+    assert (status == 0).all()
+    np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(ref).max()))
+
+
+def test_shift_is_rejected_where_it_does_not_apply(native):
+    inp = synthetic.make_kernel_inputs(5, 20, 2, seed=3)
+    dev = native.default_device()
+    b = native.Batch(dev, "conjugate", 5, 20, inp["n_r"], 5.0, 2, inp["m"])
+    with pytest.raises(Exception, match="Jeffreys"):
+        b.set_shift(np.ones((2, 2)))
+    b.close()
+    b = native.Batch(dev, "jeffreys", 5, 20, inp["n_r"], 5.0, 2, 0)
+    with pytest.raises(Exception, match=">= 0"):
+        b.set_shift(np.array([[1.0, -1.0], [0.0, 0.0]]))
+    b.close()
