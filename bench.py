@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--windows", type=int, default=0, help="override windows per GPU")
     ap.add_argument("--strategy", default="conjugate", choices=["conjugate", "jeffreys"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-gather", action="store_true",
+                    help="N=1 only: run the N>1 step (RCCL gather on the second stream + its verification) on a "
+                         "one-rank communicator; for rehearsing the multi-GPU code path on a one-GPU box")
     args = ap.parse_args()
 
     cp = shard.ControlPlane()
@@ -72,6 +75,9 @@ def main():
     # one GPU per rank; on a box with fewer GPUs than ranks (rehearsals) ranks wrap around
     dev = _native.Device(cp.local_rank % max(1, _native.device_count()))
     gather_mode = "none"
+    if cp.world == 1 and args.rehearse_gather:
+        shard.init_rccl(dev, cp)
+        gather_mode = "rccl"
     if cp.world > 1:
         try:
             shard.init_rccl(dev, cp)
@@ -93,7 +99,8 @@ def main():
     def step():
         batch.run()
         if gather_mode == "rccl":
-            batch.gather(root=0, to_host=False)      # gathered weights stay in rank 0's HBM, like N=1
+            batch.gather_async(root=0)   # on the gather stream: overlaps the next step's kernel; the gathered
+                                         # weights stay in rank 0's HBM, like N=1; dev.synchronize() waits for it
         elif gather_mode == "host-gloo":
             wts, st, _ = batch.download(want_aux=False)
             cp.gather_host(wts, root=0)
@@ -118,10 +125,16 @@ def main():
     weights, status, aux = batch.download()
     d2h_ms = dev.last_timing()["d2h_ms"]
     gathered_ok = None
-    if gather_mode == "rccl" and cp.rank == 0:
-        wall, sall = batch.download_gathered()                   # after the timed region: check the collective
-        gathered_ok = bool(np.array_equal(wall[0], weights) and np.array_equal(sall[0], status)
-                           and np.isfinite(wall).all())
+    if gather_mode == "rccl":
+        # after the timed region: check the collective - every rank's slice on root against a checksum of
+        # what that rank computed (control plane), rank 0's slice element by element
+        sums = cp.gather_host(np.array([weights.sum(), np.abs(weights).sum(), float(status.sum())]), root=0)
+        if cp.rank == 0:
+            wall, sall = batch.download_gathered()
+            gathered_ok = bool(np.array_equal(wall[0], weights) and np.array_equal(sall[0], status)
+                               and np.isfinite(wall).all()
+                               and all(wall[r].sum() == sums[r][0] and np.abs(wall[r]).sum() == sums[r][1]
+                                       and float(sall[r].sum()) == sums[r][2] for r in range(cp.world)))
     n_bad = int((status != 0).sum())
     launch = dev.last_launch()
     info = dev.info()
@@ -206,7 +219,7 @@ def main():
             "windows_with_nonzero_status": n_bad,
             "launch": launch,
             "device": info["name"].strip() or "AMD Instinct MI355X",
-            "h2d_ms": h2d_ms, "d2h_ms": d2h_ms, "gather_ms": tim["gather_ms"] if cp.world > 1 else None,
+            "h2d_ms": h2d_ms, "d2h_ms": d2h_ms, "gather_ms": tim["gather_ms"] if gather_mode == "rccl" else None,
             "host": {"cpus": len(os.sched_getaffinity(0))},
         }
         sys.stdout.flush()

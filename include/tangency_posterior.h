@@ -176,6 +176,12 @@ int tp_comm_destroy(tp_handle_t h);
  * statuses stay in root's HBM; weights_all / status_all are optional HOST buffers on root (NULL: no
  * copy-out, fetch later with tp_batch_download_gathered). */
 int tp_batch_gather(tp_batch_t b, int root, double* weights_all, int32_t* status_all);
+/* The same gather without waiting for it, on a second, high-priority stream: from its first use the batch
+ * keeps TWO result buffers and tp_batch_run alternates between them, so the gather of step i reads one while
+ * the kernel of step i+1 writes the other (a rebalancing schedule that streams batches); no copy is made.
+ * Returns at once; tp_synchronize (or tp_batch_download_gathered) waits for it.  Gathers complete in the
+ * order they were issued; tp_batch_download always reads the results of the last run. */
+int tp_batch_gather_async(tp_batch_t b, int root);
 int tp_batch_download_gathered(tp_batch_t b, double* weights_all, int32_t* status_all); /* root only */
 
 #ifdef __cplusplus

@@ -35,7 +35,7 @@ EXPORTS = [
     "tp_batch_create", "tp_batch_upload", "tp_batch_set_rhs", "tp_batch_set_shift", "tp_batch_download_rhs", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1", "tp_batch_download_matrix", "tp_batch_debug_stamps",
     "tp_batch_destroy", "tp_posterior_batch", "tp_synchronize", "tp_last_timing", "tp_region_begin",
     "tp_region_end", "tp_last_launch", "tp_comm_unique_id", "tp_comm_init", "tp_comm_destroy",
-    "tp_batch_gather", "tp_batch_download_gathered",
+    "tp_batch_gather", "tp_batch_gather_async", "tp_batch_download_gathered",
 ]
 
 
@@ -94,6 +94,7 @@ def _load():
     lib.tp_comm_init.argtypes = [c_void_p, c_void_p, c_int, c_int]
     lib.tp_comm_destroy.argtypes = [c_void_p]
     lib.tp_batch_gather.argtypes = [c_void_p, c_int, POINTER(c_double), POINTER(c_int32)]
+    lib.tp_batch_gather_async.argtypes = [c_void_p, c_int]
     lib.tp_batch_download_gathered.argtypes = [c_void_p, POINTER(c_double), POINTER(c_int32)]
     for name in EXPORTS:
         fn = getattr(lib, name)
@@ -322,6 +323,13 @@ class Batch:
             return wall, sall
         self.dev._check(lib.tp_batch_gather(self._b, root, None, None))
         return None, None
+
+    def gather_async(self, root=0):
+        """The same gather on the handle's second stream, not waited for: it overlaps the next `run`.
+        `Device.synchronize()` or `download_gathered()` wait for it."""
+        self._gather_root = root
+        self.dev._check(lib.tp_batch_gather_async(self._b, root))
+        return self
 
     def download_gathered(self):
         world = self.dev.world

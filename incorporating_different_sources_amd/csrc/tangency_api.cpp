@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <new>
 #include <string>
 #include <vector>
@@ -34,6 +35,10 @@ struct tp_handle_s {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     bool kernel_timed = false;   // ev0/ev1 bracket the last tp_batch_run and have not been read yet
+    // overlapped gather (tp_batch_gather_async): its own high-priority stream next to the kernel stream
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t snap = nullptr, cg0 = nullptr, cg1 = nullptr;
+    bool gather_timed = false;      // cg0/cg1 bracket the last asynchronous gather and have not been read yet
 };
 
 struct DevBuf {
@@ -47,11 +52,19 @@ struct tp_batch_s {
     int64_t W = 0;
     int panel_ld = 0, hf_ld = 0;
     DevBuf panel, start, row_idx, n_rows, col_idx, rf_adj, hf_panel, hf_start, hf_row_idx, hf_count, w0, n0;
-    DevBuf weights, status, aux, dbg, gather_w, gather_s, stamps, rhs, out_rhs, shift;
+    DevBuf weights, status, aux, dbg, gather_w, gather_s, weights2, status2, stamps, rhs, out_rhs, shift;
     DevBuf t_arena, t_rinv, t_ybar, t_zc, t_scal, t_flags;   // large-k path workspace
     int64_t tiled_capacity = 0;                               // windows in flight per sub-batch
     bool uploaded = false;
     bool gathered = false;
+    // tp_batch_gather_async: results alternate between (weights, status) and (weights2, status2), so that the
+    // gather of run i reads one pair while run i+1 writes the other; run i+2 waits for that gather's event
+    bool pingpong = false;
+    int parity = 0;                                  // pair written by the last run
+    hipEvent_t gather_done[2] = {nullptr, nullptr};
+    bool gather_pending[2] = {false, false};
+    double* out_weights() const { return (double*)(parity ? weights2.p : weights.p); }
+    int32_t* out_status() const { return (int32_t*)(parity ? status2.p : status.p); }
 };
 
 namespace {
@@ -134,8 +147,8 @@ tp_kargs_t make_kargs(tp_batch_t b) {
 #ifdef TP_STAMP
     { const char* pl = getenv("TP_PHASE_LIMIT"); a.phase_limit = pl ? atoi(pl) : 0; }   // diagnostic build only
 #endif
-    a.weights = (double*)b->weights.p;
-    a.status = (int*)b->status.p;
+    a.weights = b->out_weights();
+    a.status = (int*)b->out_status();
     a.aux = (double*)b->aux.p;
     a.out_rhs = (double*)b->out_rhs.p;
     a.stamps = (long long*)b->stamps.p;
@@ -311,8 +324,12 @@ int tp_create(int device_id, tp_handle_t* out) {
 int tp_destroy(tp_handle_t h) {
     if (!h) return TP_OK;
     (void)hipSetDevice(h->device);
+    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipEvent_t e : {h->snap, h->cg0, h->cg1})
+        if (e) (void)hipEventDestroy(e);
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->reg0) (void)hipEventDestroy(h->reg0);
@@ -352,9 +369,12 @@ int tp_batch_destroy(tp_batch_t b) {
     if (!b) return TP_OK;
     (void)hipSetDevice(b->h->device);
     (void)hipStreamSynchronize(b->h->stream);
+    if (b->h->comm_stream) (void)hipStreamSynchronize(b->h->comm_stream);   // a gather may still read the results
+    for (hipEvent_t e : b->gather_done)
+        if (e) (void)hipEventDestroy(e);
     DevBuf* all[] = {&b->panel, &b->start, &b->row_idx, &b->n_rows, &b->col_idx, &b->rf_adj, &b->hf_panel, &b->hf_start,
                      &b->hf_row_idx, &b->hf_count, &b->w0, &b->n0, &b->weights, &b->status, &b->aux, &b->dbg,
-                     &b->gather_w, &b->gather_s, &b->stamps, &b->rhs, &b->out_rhs, &b->shift, &b->t_arena, &b->t_rinv, &b->t_ybar, &b->t_zc,
+                     &b->gather_w, &b->gather_s, &b->weights2, &b->status2, &b->stamps, &b->rhs, &b->out_rhs, &b->shift, &b->t_arena, &b->t_rinv, &b->t_ybar, &b->t_zc,
                      &b->t_scal, &b->t_flags};
     for (DevBuf* d : all) release(*d);
     delete b;
@@ -451,6 +471,13 @@ int tp_batch_run(tp_batch_t b) {
     tp_handle_t h = b->h;
     if (!b->uploaded) return fail(h, TP_ERR_INVALID, "tp_batch_run before tp_batch_upload");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (b->pingpong) {
+        b->parity ^= 1;
+        if (b->gather_pending[b->parity]) {          // the gather issued two runs ago read this pair
+            HIP_TRY(h, hipStreamWaitEvent(h->stream, b->gather_done[b->parity], 0));
+            b->gather_pending[b->parity] = false;
+        }
+    }
     tp_kargs_t a = make_kargs(b);
     return launch(b, a, b->W, true);
 }
@@ -466,10 +493,26 @@ static int harvest_kernel_time(tp_handle_t h) {
     return TP_OK;
 }
 
+static int harvest_gather_time(tp_handle_t h) {
+    if (h->gather_timed) {
+        HIP_TRY(h, hipEventSynchronize(h->cg1));
+        float ms = 0;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->cg0, h->cg1));
+        h->gather_ms = ms;
+        h->gather_timed = false;
+    }
+    return TP_OK;
+}
+
 int tp_synchronize(tp_handle_t h) {
     if (!h) return TP_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->comm_stream) {
+        HIP_TRY(h, hipStreamSynchronize(h->comm_stream));
+        int rc = harvest_gather_time(h);
+        if (rc != TP_OK) return rc;
+    }
     return harvest_kernel_time(h);
 }
 
@@ -481,8 +524,8 @@ int tp_batch_download(tp_batch_t b, double* weights, int32_t* status, double* au
     int rc = harvest_kernel_time(h);
     if (rc != TP_OK) return rc;
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    if (weights) HIP_TRY(h, hipMemcpyAsync(weights, b->weights.p, sizeof(double) * (size_t)b->W * b->p.k, hipMemcpyDeviceToHost, h->stream));
-    if (status) HIP_TRY(h, hipMemcpyAsync(status, b->status.p, sizeof(int32_t) * (size_t)b->W, hipMemcpyDeviceToHost, h->stream));
+    if (weights) HIP_TRY(h, hipMemcpyAsync(weights, b->out_weights(), sizeof(double) * (size_t)b->W * b->p.k, hipMemcpyDeviceToHost, h->stream));
+    if (status) HIP_TRY(h, hipMemcpyAsync(status, b->out_status(), sizeof(int32_t) * (size_t)b->W, hipMemcpyDeviceToHost, h->stream));
     if (aux) HIP_TRY(h, hipMemcpyAsync(aux, b->aux.p, sizeof(double) * (size_t)b->W * TP_AUX_STRIDE, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     HIP_TRY(h, hipEventSynchronize(h->ev1));
@@ -615,6 +658,7 @@ int tp_comm_init(tp_handle_t h, const void* id, int rank, int world) {
 
 int tp_comm_destroy(tp_handle_t h) {
     if (!h) return TP_ERR_INVALID;
+    if (h->comm_stream) { HIP_TRY(h, hipSetDevice(h->device)); HIP_TRY(h, hipStreamSynchronize(h->comm_stream)); }
     if (h->comm) { NCCL_TRY(h, ncclCommDestroy(h->comm)); h->comm = nullptr; }
     h->world = 1; h->rank = 0;
     return TP_OK;
@@ -639,8 +683,8 @@ int tp_batch_gather(tp_batch_t b, int root, double* weights_all, int32_t* status
     HIP_TRY(h, hipEventRecord(g0, h->stream));
     // one gather of the weights (and one of the statuses) to root, on the stream of the kernel
     NCCL_TRY(h, ncclGroupStart());
-    NCCL_TRY(h, ncclGather(b->weights.p, is_root ? b->gather_w.p : nullptr, nw, ncclDouble, root, h->comm, h->stream));
-    NCCL_TRY(h, ncclGather(b->status.p, is_root ? b->gather_s.p : nullptr, ns, ncclInt32, root, h->comm, h->stream));
+    NCCL_TRY(h, ncclGather(b->out_weights(), is_root ? b->gather_w.p : nullptr, nw, ncclDouble, root, h->comm, h->stream));
+    NCCL_TRY(h, ncclGather(b->out_status(), is_root ? b->gather_s.p : nullptr, ns, ncclInt32, root, h->comm, h->stream));
     NCCL_TRY(h, ncclGroupEnd());
     HIP_TRY(h, hipEventRecord(g1, h->stream));
     HIP_TRY(h, hipEventSynchronize(g1));
@@ -656,11 +700,64 @@ int tp_batch_gather(tp_batch_t b, int root, double* weights_all, int32_t* status
     return TP_OK;
 }
 
+int tp_batch_gather_async(tp_batch_t b, int root) {
+    if (!b) return TP_ERR_INVALID;
+    tp_handle_t h = b->h;
+    if (!h->comm) return fail(h, TP_ERR_INVALID, "tp_batch_gather_async without tp_comm_init");
+    if (root < 0 || root >= h->world) return fail(h, TP_ERR_INVALID, "bad root %d", root);
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->comm_stream) {
+        int lo = 0, hi = 0;                            // numerically lower = higher priority
+        HIP_TRY(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(h, hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, hi));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->snap, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreate(&h->cg0));
+        HIP_TRY(h, hipEventCreate(&h->cg1));
+    }
+    const size_t nw = (size_t)b->W * b->p.k, ns = (size_t)b->W;
+    const bool is_root = h->rank == root;
+    int rc = TP_OK;
+    if (!b->pingpong) {                                // first use: the second result pair and its events
+        rc = ensure(h, b->weights2, sizeof(double) * nw);
+        if (rc == TP_OK) rc = ensure(h, b->status2, sizeof(int32_t) * ns);
+        if (rc != TP_OK) return rc;
+        for (hipEvent_t& e : b->gather_done) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        b->pingpong = true;
+    }
+    if (is_root) rc = ensure(h, b->gather_w, sizeof(double) * nw * h->world);
+    if (rc == TP_OK && is_root) rc = ensure(h, b->gather_s, sizeof(int32_t) * ns * h->world);
+    if (rc != TP_OK) return rc;
+    // timing events: re-record them only when the previous pair has been read or is already complete - the
+    // host must never wait here, or the gather of step i-1 would serialise with the launch of step i+1
+    bool time_this = true;
+    if (h->gather_timed) {
+        if (hipEventQuery(h->cg1) == hipSuccess) { rc = harvest_gather_time(h); if (rc != TP_OK) return rc; }
+        else time_this = false;
+    }
+    // gather stream: wait for the run that produced this pair, then one gather of the weights and one of the
+    // statuses to root.  No copy: the next run writes the OTHER pair.
+    HIP_TRY(h, hipEventRecord(h->snap, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->comm_stream, h->snap, 0));
+    if (time_this) HIP_TRY(h, hipEventRecord(h->cg0, h->comm_stream));
+    NCCL_TRY(h, ncclGroupStart());
+    NCCL_TRY(h, ncclGather(b->out_weights(), is_root ? b->gather_w.p : nullptr, nw, ncclDouble, root, h->comm, h->comm_stream));
+    NCCL_TRY(h, ncclGather(b->out_status(), is_root ? b->gather_s.p : nullptr, ns, ncclInt32, root, h->comm, h->comm_stream));
+    NCCL_TRY(h, ncclGroupEnd());
+    if (time_this) { HIP_TRY(h, hipEventRecord(h->cg1, h->comm_stream)); h->gather_timed = true; }
+    HIP_TRY(h, hipEventRecord(b->gather_done[b->parity], h->comm_stream));
+    b->gather_pending[b->parity] = true;
+    b->gathered = true;
+    return TP_OK;
+}
+
 int tp_batch_download_gathered(tp_batch_t b, double* weights_all, int32_t* status_all) {
     if (!b) return TP_ERR_INVALID;
     tp_handle_t h = b->h;
     if (!b->gathered || !b->gather_w.p) return fail(h, TP_ERR_INVALID, "nothing gathered on this rank (root only, after tp_batch_gather)");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->comm_stream) {                              // an asynchronous gather may still be filling gather_w
+        HIP_TRY(h, hipStreamSynchronize(h->comm_stream));
+    }
     const size_t nw = (size_t)b->W * b->p.k, ns = (size_t)b->W;
     if (weights_all) HIP_TRY(h, hipMemcpyAsync(weights_all, b->gather_w.p, sizeof(double) * nw * h->world, hipMemcpyDeviceToHost, h->stream));
     if (status_all) HIP_TRY(h, hipMemcpyAsync(status_all, b->gather_s.p, sizeof(int32_t) * ns * h->world, hipMemcpyDeviceToHost, h->stream));

@@ -112,6 +112,41 @@ def test_rccl_gather_world_1(native):
         dev.close()
 
 
+def test_rccl_gather_async_overlaps_and_orders(native):
+    """tp_batch_gather_async on a one-rank communicator: several run + gather pairs queued without a host
+    wait; each gather sees the snapshot of ITS run even though the next run rewrites the weights (the
+    right-hand side changes between runs), and the last one is what download_gathered returns."""
+    k, N, W = 20, 50, 200
+    inp = synthetic.make_kernel_inputs(k, N, W, seed=98)
+    dev = native.Device(0)
+    try:
+        dev.comm_init(native.Device.comm_unique_id(), 0, 1)
+        b = dev.batch("jeffreys", k, N, inp["n_r"], 5.0, W, 0)
+        b.upload(panel=inp["panel"], start=inp["start"])
+        expect = None
+        for i in range(4):
+            b.set_rhs(np.full((W, k), float(i + 1)))
+            b.run()
+            b.gather_async(root=0)
+        dev.synchronize()
+        wall, sall = b.download_gathered()
+        w, s, _ = b.download()
+        assert np.array_equal(wall[0], w) and np.array_equal(sall[0], s)
+        assert dev.last_timing()["gather_ms"] > 0
+        # queued back to back WITHOUT set_rhs' host synchronisation in between: run(i+1) overwrites the weights
+        # while gather(i) may still be in flight; linearity in the right-hand side identifies the snapshot
+        b.set_rhs(np.full((W, k), 1.0)); b.run(); b.gather_async(root=0)
+        first, _ = b.download_gathered()
+        b.set_rhs(np.full((W, k), 3.0))
+        b.run(); b.gather_async(root=0); b.run(); b.gather_async(root=0)
+        last, _ = b.download_gathered()
+        np.testing.assert_allclose(last[0], 3.0 * first[0], rtol=1e-12, atol=0)
+        b.close()
+        dev.comm_destroy()
+    finally:
+        dev.close()
+
+
 def test_status_codes(native):
     """Rank-deficient windows are flagged, not returned as garbage (Appendix B-Q8): Jeffreys with
     k > n_r - 1 has a singular J; a conjugate window with too few intraday returns likewise."""
