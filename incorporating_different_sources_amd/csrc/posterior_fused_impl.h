@@ -98,7 +98,8 @@ struct Cfg {
     static constexpr int OFF_WVEC = OFF_YVEC + KP;       // [KP] solution
     static constexpr int OFF_DIAG = OFF_WVEC + KP;       // 2 x [16][16] diagonal tile handed to the eliminating wave
     static constexpr int OFF_SCAL = OFF_DIAG + 512;      // [8] scalars: 0 = z'z, 1 = not-positive-definite flag
-    static constexpr int LDS_DOUBLES = OFF_SCAL + 8;
+    static constexpr int OFF_COFF = OFF_SCAL + 8;        // [KP] uint32: byte offsets 8*col_idx[c] of the gathered columns
+    static constexpr int LDS_DOUBLES = OFF_COFF + KP / 2;
     static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
 };
 
@@ -223,37 +224,78 @@ struct RowSource {
     long long first;        // first row (contiguous mode)
     const double* sub_row;  // per-row subtrahend (rf_adj) or nullptr
     int count;              // rows of this window
+    bool off32;             // every byte offset from `base` (explicit rows) / from the window's first row fits 32 bits
 };
+
+// ---- staging.  VALU instructions are the scarce resource of this kernel: on gfx950 a wavefront streaming
+// fp64 MFMAs lets the SIMD's other wavefronts issue about ONE vector instruction per MFMA (tools/
+// coexec_probe.hip), so every v_* spent on addresses, masks or selects is paid in MFMA time.  Hence:
+//  * addresses are ONE 32-bit offset per row (v_mad_u32_u24) on a uniform 64-bit base (scalar registers);
+//    the 16-column groups are immediate offsets, gathered columns come from a byte-offset table in LDS;
+//  * row masks exist only in the ragged last chunk (`full` is wave-uniform), column masks only in the
+//    last 16-column group.
 
 // Issue the global loads of one staged chunk: RAW values only.  Nothing here may consume a loaded
 // value (no subtraction, no select): any use would make the compiler wait for the loads right here
 // and the prefetch under the MFMA block would be lost (it was: 4.4 k cycles per chunk).  Masking,
 // centring and the risk-free subtraction happen in store_chunk, after the MFMAs.
 template <class C, bool HF>
-__device__ __forceinline__ void load_chunk(const RowSource& src, const int* __restrict__ cols, int k, int chunk,
-                                           int tid, double (&v)[C::PASSES][C::NT], double (&sub)[C::PASSES]) {
+__device__ __forceinline__ void load_chunk(const RowSource& src, const int* __restrict__ cols,
+                                           const unsigned* __restrict__ coff, int k, int chunk, int tid, bool full,
+                                           double (&v)[C::PASSES][C::NT], double (&sub)[C::PASSES]) {
     const int cb = tid & 15;
-    // Column offsets first, under ONE uniform branch: with the select inside the load loop the
-    // compiler merged the two paths per element and put an s_waitcnt vmcnt(0) in front of every data
-    // load (7 serialised L2 round trips per chunk).
+    constexpr int kI = C::NT - 1;
+    if (src.off32) {
+        // uniform base: the window's first row (contiguous rows) or the panel (explicit rows)
+        const char* ub = (const char*)(src.ridx ? src.base : src.base + src.first * (long long)src.ld);
+        const unsigned ld8 = (unsigned)src.ld * 8u;
+        unsigned co[C::NT];
+        if (cols) {
+#pragma unroll
+            for (int i = 0; i < C::NT; ++i) co[i] = coff[cb + 16 * i];       // padding columns repeat column k-1
+        } else {
+            const int cl = cb + 16 * kI;
+            co[kI] = 8u * (unsigned)(cl < k ? cl : k - 1);                   // k >= 16 (NT-1): only the last group clamps
+        }
+#pragma unroll
+        for (int ps = 0; ps < C::PASSES; ++ps) {
+            const int r = chunk * C::CH + ps * C::ROWS_PER_PASS + (tid >> 4);
+            const int rc = (full || r < src.count) ? r : src.count - 1;      // clamp (count >= 1 is validated on the host)
+            const unsigned row = src.ridx ? (unsigned)src.ridx[rc] : (unsigned)rc;
+            sub[ps] = 0.0;
+            if (!HF && src.sub_row) sub[ps] = src.sub_row[rc];
+            const unsigned ro = __umul24(row, ld8);          // rows, 8 ld < 2^24 (checked on the host)
+            if (cols) {
+#pragma unroll
+                for (int i = 0; i < C::NT; ++i) v[ps][i] = *(const double*)(ub + (size_t)(ro + co[i]));
+            } else {
+                const unsigned o = ro + 8u * (unsigned)cb;
+#pragma unroll
+                for (int i = 0; i < kI; ++i) v[ps][i] = *(const double*)(ub + (size_t)o + 128 * i);
+                v[ps][kI] = *(const double*)(ub + (size_t)(ro + co[kI]));
+            }
+        }
+        return;
+    }
+    // explicit rows in a panel of 4 GiB or more: 64-bit addresses
     int ci[C::NT];
     if (cols) {
 #pragma unroll
         for (int i = 0; i < C::NT; ++i) {
             const int c = cb + 16 * i;
-            ci[i] = cols[((i < C::NT - 1) || (c < k)) ? c : k - 1];
+            ci[i] = cols[((i < kI) || (c < k)) ? c : k - 1];
         }
     } else {
 #pragma unroll
         for (int i = 0; i < C::NT; ++i) {
             const int c = cb + 16 * i;
-            ci[i] = ((i < C::NT - 1) || (c < k)) ? c : k - 1;   // k >= 16 (NT-1): only the last group needs the clamp
+            ci[i] = ((i < kI) || (c < k)) ? c : k - 1;
         }
     }
 #pragma unroll
     for (int ps = 0; ps < C::PASSES; ++ps) {
         const int r = chunk * C::CH + ps * C::ROWS_PER_PASS + (tid >> 4);
-        const int rc = (r < src.count) ? r : src.count - 1;   // clamp (count >= 1 is validated on the host)
+        const int rc = (r < src.count) ? r : src.count - 1;
         const long long row = src.ridx ? (long long)src.ridx[rc] : src.first + rc;
         sub[ps] = 0.0;
         if (!HF && src.sub_row) sub[ps] = src.sub_row[rc];
@@ -264,37 +306,46 @@ __device__ __forceinline__ void load_chunk(const RowSource& src, const int* __re
 }
 
 // Finish the staged values in registers (centre / z column for HF, ones column for daily) and write
-// them to the LDS staging buffer.
+// them to the LDS staging buffer.  `full`: every row of the chunk is a real row (wave-uniform).
 template <class C, bool HF>
 __device__ __forceinline__ void store_chunk(double* __restrict__ buf, const double* __restrict__ lds, int k,
-                                            int chunk, int count, int tid, double (&v)[C::PASSES][C::NT],
-                                            const double (&sub)[C::PASSES]) {
+                                            int chunk, int count, int tid, bool full, bool has_sub,
+                                            double (&v)[C::PASSES][C::NT], const double (&sub)[C::PASSES]) {
     const int cb = tid & 15;
     constexpr int kI = C::NT - 1;            // the border column k always lies in the last 16-column group
     const int kc = k - 16 * kI;
+    const bool cvl = cb < kc;                // column validity in the last group
 #pragma unroll
     for (int ps = 0; ps < C::PASSES; ++ps) {
         const int rl = ps * C::ROWS_PER_PASS + (tid >> 4);
-        const bool rv = chunk * C::CH + rl < count;
         if (HF) {
             double z = 0.0;
 #pragma unroll
             for (int i = 0; i < C::NT; ++i) {
                 const int c = cb + 16 * i;
-                const bool cv = (i < kI) || (c < k);
-                v[ps][i] = (rv && cv) ? v[ps][i] - lds[C::OFF_YBAR + c] : 0.0;   // ybar, w0 are zero-padded
-                z = fma(v[ps][i], lds[C::OFF_W0 + c], z);
+                v[ps][i] -= lds[C::OFF_YBAR + c];                            // ybar, w0 are zero-padded
+                if (i == kI) v[ps][i] = cvl ? v[ps][i] : 0.0;
             }
+            if (!full) {
+                const bool rv = chunk * C::CH + rl < count;
+#pragma unroll
+                for (int i = 0; i < C::NT; ++i) v[ps][i] = rv ? v[ps][i] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < C::NT; ++i) z = fma(v[ps][i], lds[C::OFF_W0 + cb + 16 * i], z);
             z = rowgroup_sum16(z);
             if (cb == kc) v[ps][kI] = z;                 // border column: z_r = (y_r - ybar).w0
         } else {
+            if (has_sub) {
 #pragma unroll
-            for (int i = 0; i < C::NT; ++i) {
-                const int c = cb + 16 * i;
-                const bool cv = (i < kI) || (c < k);
-                v[ps][i] = (rv && cv) ? v[ps][i] - sub[ps] : 0.0;          // ref:57
+                for (int i = 0; i < C::NT; ++i) v[ps][i] -= sub[ps];         // ref:57
             }
-            if (cb == kc) v[ps][kI] = rv ? 1.0 : 0.0;    // border column: ones -> t = X'1
+            v[ps][kI] = cvl ? v[ps][kI] : ((cb == kc) ? 1.0 : 0.0);          // border column: ones -> t = X'1
+            if (!full) {
+                const bool rv = chunk * C::CH + rl < count;
+#pragma unroll
+                for (int i = 0; i < C::NT; ++i) v[ps][i] = rv ? v[ps][i] : 0.0;
+            }
         }
 #pragma unroll
         for (int i = 0; i < C::NT; ++i) buf[rl * C::LDX + cb + 16 * i] = v[ps][i];
@@ -311,10 +362,10 @@ __device__ __forceinline__ void mfma_tiles(const double* __restrict__ lanebase, 
         for_tiles<C, WV>([&](auto sc, auto Ic, auto Jc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
             if (pick(I, J)) {
-                double a = lanebase[4 * s4 * C::LDX + 16 * I];
+                const double a = lanebase[4 * s4 * C::LDX + 16 * I];
                 const double b = lanebase[4 * s4 * C::LDX + 16 * J];
-                if (NEG) a = -a;
-                acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[s], 0, 0, 0);
+                // f64 MFMAs reuse the BLGP field as negate bits (bit 0: A): acc -= a'b without a vector negate
+                acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[s], 0, 0, NEG ? 1 : 0);
             }
         });
     }
@@ -337,10 +388,13 @@ __device__ __forceinline__ void gram_phase(const RowSource& src, const int* __re
     const int nchunks = (src.count + C::CH - 1) / C::CH;
     double v[C::PASSES][C::NT];
     double sub[C::PASSES];
+    const unsigned* coff = (const unsigned*)(lds + C::OFF_COFF);
+    const bool has_sub = !HF && src.sub_row != nullptr;
     if (nchunks > 0) {
         const int tid = fresh(tid0);
-        load_chunk<C, HF>(src, cols, k, 0, tid, v, sub);
-        store_chunk<C, HF>(lds + C::OFF_STAGE0, lds, k, 0, src.count, tid, v, sub);
+        const bool full = C::CH <= src.count;
+        load_chunk<C, HF>(src, cols, coff, k, 0, tid, full, v, sub);
+        store_chunk<C, HF>(lds + C::OFF_STAGE0, lds, k, 0, src.count, tid, full, has_sub, v, sub);
     }
     __syncthreads();
 #pragma nounroll
@@ -350,8 +404,9 @@ __device__ __forceinline__ void gram_phase(const RowSource& src, const int* __re
         double* cur = lds + ((ch & 1) ? C::OFF_STAGE1 : C::OFF_STAGE0);
         double* nxt = lds + ((ch & 1) ? C::OFF_STAGE0 : C::OFF_STAGE1);
         const bool more = ch + 1 < nchunks;
+        const bool full = (ch + 2) * C::CH <= src.count;                       // chunk ch+1 has no ragged rows
         TP_LOOPSTAMP(0);
-        if (more) load_chunk<C, HF>(src, cols, k, ch + 1, tid, v, sub);       // global loads in flight under the MFMAs
+        if (more) load_chunk<C, HF>(src, cols, coff, k, ch + 1, tid, full, v, sub);   // global loads in flight under the MFMAs
         __builtin_amdgcn_sched_barrier(0);   // the scheduler must not sink these loads below the MFMA block
         TP_LOOPSTAMP(1);
         const double* lanebase = cur + fq * C::LDX + fr;
@@ -359,7 +414,7 @@ __device__ __forceinline__ void gram_phase(const RowSource& src, const int* __re
             mfma_tiles<C, decltype(wc)::value, C::CH, false>(lanebase, acc, [](int, int) { return true; });
         });
         TP_LOOPSTAMP(2);
-        if (more) store_chunk<C, HF>(nxt, lds, k, ch + 1, src.count, tid, v, sub);
+        if (more) store_chunk<C, HF>(nxt, lds, k, ch + 1, src.count, tid, full, has_sub, v, sub);
         TP_LOOPSTAMP(3);
         __syncthreads();
         TP_LOOPSTAMP(4);
@@ -393,6 +448,13 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
 
     const int* cols = A.col_idx ? A.col_idx + w * k : nullptr;
     d4 acc[C::SLOTS];
+    unsigned* coff = (unsigned*)(lds + C::OFF_COFF);
+    if (cols) {
+        // byte offsets of the gathered columns, once per window; padding columns repeat column k-1 (their
+        // values are masked in store_chunk) so that every load address is a real element
+        for (int c = tid0; c < C::KP; c += C::NTHREADS) coff[c] = 8u * (unsigned)cols[c < k ? c : k - 1];
+        __syncthreads();
+    }
 
     double n0 = 0.0, cc = 0.0, q0 = 0.0;
     const bool conj = A.strategy == 0;
@@ -429,6 +491,7 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
         hs.first = A.hf_start ? A.hf_start[w] : 0;
         hs.sub_row = nullptr;
         hs.count = A.hf_count ? A.hf_count[w] : A.m;
+        hs.off32 = (A.hf_off32 & (hs.ridx ? 1 : 2)) != 0;
         TP_MARK(0);
         // ---- phase A: column means (ref:317, DataFrame.cov centres first) and w0 into LDS.
         // Same thread geometry as the staging (16 threads per row, 16-lane coalesced segments): every
@@ -439,30 +502,28 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
 #pragma unroll
             for (int i = 0; i < C::NT; ++i) cs[i] = 0.0;
             const int cb = tid & 15;
-            const int iters = (hs.count + C::ROWS_PER_PASS - 1) / C::ROWS_PER_PASS;
-            int ci[C::NT];
-            bool cv[C::NT];
-#pragma unroll
-            for (int i = 0; i < C::NT; ++i) {
-                const int c = cb + 16 * i;
-                cv[i] = (i < C::NT - 1) || (c < k);
-                ci[i] = cv[i] ? c : k - 1;                                  // clamp: load unconditionally
-            }
-            if (cols) {
-#pragma unroll
-                for (int i = 0; i < C::NT; ++i) ci[i] = cols[ci[i]];
-            }
+            // same loads as the staging (load_chunk); full chunks need no mask at all (the padding columns'
+            // sums are dropped when ybar is written), only the ragged last chunk masks its rows
+            const int nfull = hs.count / C::CH;
 #pragma unroll 4
-            for (int it = 0; it < iters; ++it) {                            // loads of 4 iterations in flight
-                const int r = it * C::ROWS_PER_PASS + (tid >> 4);
-                const bool rv = r < hs.count;
-                const int rc = rv ? r : hs.count - 1;
-                const long long row = hs.ridx ? (long long)hs.ridx[rc] : hs.first + rc;
-                const double* p = hs.base + row * (long long)hs.ld;
+            for (int ch = 0; ch < nfull; ++ch) {                            // loads of 4 chunks in flight
+                double v[C::PASSES][C::NT];
+                double sub[C::PASSES];
+                load_chunk<C, true>(hs, cols, coff, k, ch, tid, true, v, sub);
 #pragma unroll
-                for (int i = 0; i < C::NT; ++i) {
-                    const double x = p[ci[i]];
-                    cs[i] += (rv && cv[i]) ? x : 0.0;
+                for (int ps = 0; ps < C::PASSES; ++ps)
+#pragma unroll
+                    for (int i = 0; i < C::NT; ++i) cs[i] += v[ps][i];
+            }
+            if (nfull * C::CH < hs.count) {
+                double v[C::PASSES][C::NT];
+                double sub[C::PASSES];
+                load_chunk<C, true>(hs, cols, coff, k, nfull, tid, false, v, sub);
+#pragma unroll
+                for (int ps = 0; ps < C::PASSES; ++ps) {
+                    const bool rv = nfull * C::CH + ps * C::ROWS_PER_PASS + (tid >> 4) < hs.count;
+#pragma unroll
+                    for (int i = 0; i < C::NT; ++i) cs[i] += rv ? v[ps][i] : 0.0;
                 }
             }
             double* part = lds + C::OFF_STAGE0;                             // [ROWS_PER_PASS][LDX]
@@ -540,6 +601,7 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
         ds.first = A.start ? A.start[w] : 0;
         ds.sub_row = A.rf_adj ? A.rf_adj + w * (long long)A.n_r : nullptr;
         ds.count = A.n_rows ? A.n_rows[w] : A.n_r;
+        ds.off32 = (A.panel_off32 & (ds.ridx ? 1 : 2)) != 0;
         gram_phase<C, false, FIX>(ds, cols, k, lds, tid0, wv, acc, TP_LOOPSTAMP_PTR);
     }
 

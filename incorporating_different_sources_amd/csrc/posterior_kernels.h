@@ -34,6 +34,7 @@ struct tp_kargs_t {
     int dbg_mode;         // 1 prior (S0 | c S0 w0), 2 canonical statistics (T | t), 3 posterior (S1 or J | rhs)
     long long w_first, w_count;
     int panel_ld, hf_ld;
+    int panel_off32, hf_off32;   // bit 0: explicit-row windows, bit 1: contiguous windows may use 32-bit byte offsets (u24 x u24)
     int k, N, n_r, m, strategy;
     int phase_limit;      // diagnostic (TP_PHASE_LIMIT): 1 = stop after the Gram phases (outputs are then invalid)
     int center_rows;      // Jeffreys: 0 = J = T - t t'/N, 1 = divide by the window's row count instead, 2 = plain T

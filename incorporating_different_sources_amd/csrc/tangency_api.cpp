@@ -158,6 +158,17 @@ tp_kargs_t make_kargs(tp_batch_t b) {
     a.w_count = b->W;
     a.panel_ld = b->panel_ld;
     a.hf_ld = b->hf_ld;
+    // 32-bit addressing of the staging loads: row x (8 ld) as a 24 x 24 bit product that fits 32 bits
+    auto off32 = [](size_t bytes, int ld, int rows_per_window) {
+        if (ld < 1 || (size_t)ld * 8 >= (1u << 24)) return 0;
+        const size_t rows = bytes / ((size_t)ld * 8);
+        int f = 0;
+        if (bytes < (1ull << 32) && rows < (1u << 24)) f |= 1;
+        if ((size_t)rows_per_window * ld * 8 < (1ull << 32) && (size_t)rows_per_window < (1u << 24)) f |= 2;
+        return f;
+    };
+    a.panel_off32 = off32(b->panel.bytes, b->panel_ld, b->p.n_r);
+    a.hf_off32 = b->hf_panel.p ? off32(b->hf_panel.bytes, b->hf_ld, b->p.m) : 0;
     a.k = b->p.k; a.N = b->p.N; a.n_r = b->p.n_r; a.m = b->p.m; a.strategy = b->p.strategy;
     a.gamma = b->p.gamma;
     return a;
