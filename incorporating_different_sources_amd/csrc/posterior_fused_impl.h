@@ -371,6 +371,105 @@ __device__ __forceinline__ void mfma_tiles(const double* __restrict__ lanebase, 
     }
 }
 
+// The Gram phase for contiguous rows, ungathered columns and 32-bit offsets (the layout of a rolling
+// window over one shared panel): the same loads, the same arithmetic in the same order as gram_phase below,
+// with the per-chunk vector work cut to the bone - four loop-carried lane values (row offset, its clamp,
+// the last column group's offset, the LDS write address) instead of re-deriving everything from the thread
+// id, the row clamp as ONE v_min, masks only in the ragged last chunk.
+template <class C, bool HF, int FIX>
+__device__ __forceinline__ void gram_phase_lean(const RowSource& src, int k, double* lds, int tid0, int wv,
+                                                d4 (&acc)[C::SLOTS]) {
+    constexpr int kI = C::NT - 1;
+    const int nchunks = (src.count + C::CH - 1) / C::CH;
+    const bool has_sub = !HF && src.sub_row != nullptr;
+    const char* ub = (const char*)(src.base + src.first * (long long)src.ld);      // uniform: scalar registers
+    const unsigned ld8 = (unsigned)src.ld * 8u;
+    const unsigned step = (unsigned)C::ROWS_PER_PASS * ld8;
+    const int kc = k - 16 * kI;
+    const int tid = fresh(tid0);
+    const int cb = tid & 15;
+    const int cl = cb + 16 * kI;
+    unsigned voff = __umul24((unsigned)(tid >> 4), ld8) + 8u * (unsigned)cb;       // (row, column group 0) of this lane
+    const unsigned vmax = __umul24((unsigned)(src.count - 1), ld8) + 8u * (unsigned)cb;
+    const unsigned dlast = 8u * (unsigned)((cl < k ? cl : k - 1) - cb);            // k >= 16 (NT-1): only the last group clamps
+    const unsigned wlds = (unsigned)((tid >> 4) * C::LDX + cb);
+    const bool cvl = cb < kc;
+    const double border = (!HF && cb == kc) ? 1.0 : 0.0;
+    double v[C::PASSES][C::NT];
+    double sub[C::PASSES];
+    int row = tid >> 4;                       // this lane's row in the next chunk to be loaded (pass 0)
+
+    auto load = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ps = 0; ps < C::PASSES; ++ps) {
+            const unsigned o = voff < vmax ? voff : vmax;                          // rows past the end re-read the last row
+            sub[ps] = 0.0;
+            if (has_sub) { const int r = row + ps * C::ROWS_PER_PASS; sub[ps] = src.sub_row[r < src.count ? r : src.count - 1]; }
+#pragma unroll
+            for (int i = 0; i < kI; ++i) v[ps][i] = *(const double*)(ub + (size_t)o + 128 * i);
+            v[ps][kI] = *(const double*)(ub + (size_t)(o + dlast));
+            voff += step;
+        }
+        row += C::CH;
+    };
+    auto store = [&](double* __restrict__ buf, int chunk) __attribute__((always_inline)) {
+        const bool full = (chunk + 1) * C::CH <= src.count;
+#pragma unroll
+        for (int ps = 0; ps < C::PASSES; ++ps) {
+            if (HF) {
+#pragma unroll
+                for (int i = 0; i < C::NT; ++i) v[ps][i] -= lds[C::OFF_YBAR + cb + 16 * i];    // ybar, w0 are zero-padded
+                v[ps][kI] = cvl ? v[ps][kI] : 0.0;
+            } else {
+                if (has_sub) {
+#pragma unroll
+                    for (int i = 0; i < C::NT; ++i) v[ps][i] -= sub[ps];                       // ref:57
+                }
+                v[ps][kI] = cvl ? v[ps][kI] : border;                                        // ones column -> t = X'1
+            }
+            if (!full) {
+                const bool rv = chunk * C::CH + ps * C::ROWS_PER_PASS + (tid >> 4) < src.count;
+#pragma unroll
+                for (int i = 0; i < C::NT; ++i) v[ps][i] = rv ? v[ps][i] : 0.0;
+            }
+            if (HF) {
+                double z = 0.0;
+#pragma unroll
+                for (int i = 0; i < C::NT; ++i) z = fma(v[ps][i], lds[C::OFF_W0 + cb + 16 * i], z);
+                z = rowgroup_sum16(z);
+                if (cb == kc) v[ps][kI] = z;                                                 // z_r = (y_r - ybar).w0
+            }
+#pragma unroll
+            for (int i = 0; i < C::NT; ++i) buf[wlds + ps * C::ROWS_PER_PASS * C::LDX + 16 * i] = v[ps][i];
+        }
+    };
+
+    if (nchunks > 0) {
+        load();
+        store(lds + C::OFF_STAGE0, 0);
+    }
+    __syncthreads();
+    // Accumulator tiles that were spilled across the previous phase come back by scratch loads; settle them
+    // HERE, or the counter pass puts an s_waitcnt vmcnt(0) into the MFMA loop, where it would also wait for
+    // the prefetch of the next chunk on every iteration.
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
+    const int fr = tid & 15, fq = (tid & 63) >> 4;
+#pragma nounroll
+    for (int ch = 0; ch < nchunks; ++ch) {
+        double* cur = lds + ((ch & 1) ? C::OFF_STAGE1 : C::OFF_STAGE0);
+        double* nxt = lds + ((ch & 1) ? C::OFF_STAGE0 : C::OFF_STAGE1);
+        const bool more = ch + 1 < nchunks;
+        if (more) load();                             // global loads in flight under the MFMAs
+        __builtin_amdgcn_sched_barrier(0);            // the scheduler must not sink these loads below the MFMA block
+        const double* lanebase = cur + fq * C::LDX + fr;
+        wave_sel<C::NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
+            mfma_tiles<C, decltype(wc)::value, C::CH, false>(lanebase, acc, [](int, int) { return true; });
+        });
+        if (more) store(nxt, ch + 1);
+        __syncthreads();
+    }
+}
+
 template <class C, bool HF, int FIX>
 __device__ __forceinline__ void gram_phase(const RowSource& src, const int* __restrict__ cols, int k, double* lds,
                                            int tid0, int wv, d4 (&acc)[C::SLOTS], long long* loopstamps) {
@@ -545,7 +644,8 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
             acc[decltype(sc_)::value] = d4{0.0, 0.0, 0.0, 0.0};
         });
         // ---- phase B: centred intraday Gram
-        gram_phase<C, true, FIX>(hs, cols, k, lds, tid0, wv, acc, nullptr);
+        if (!cols && !hs.ridx && hs.off32) gram_phase_lean<C, true, FIX>(hs, k, lds, tid0, wv, acc);
+        else gram_phase<C, true, FIX>(hs, cols, k, lds, tid0, wv, acc, nullptr);
         TP_MARK(2);
         // ---- phase C: q0, c, scaling (ref:333, 415-418)
         {
@@ -602,7 +702,8 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
         ds.sub_row = A.rf_adj ? A.rf_adj + w * (long long)A.n_r : nullptr;
         ds.count = A.n_rows ? A.n_rows[w] : A.n_r;
         ds.off32 = (A.panel_off32 & (ds.ridx ? 1 : 2)) != 0;
-        gram_phase<C, false, FIX>(ds, cols, k, lds, tid0, wv, acc, TP_LOOPSTAMP_PTR);
+        if (!cols && !ds.ridx && ds.off32) gram_phase_lean<C, false, FIX>(ds, k, lds, tid0, wv, acc);
+        else gram_phase<C, false, FIX>(ds, cols, k, lds, tid0, wv, acc, TP_LOOPSTAMP_PTR);
     }
 
     {
