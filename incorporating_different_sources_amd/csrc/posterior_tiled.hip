@@ -198,6 +198,7 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
 #pragma unroll
         for (int i = 0; i < 8; ++i) pcol[i] = cols[pcol[i]];
     }
+    const bool interior = MODE == MODE_GRAM && 64 * SJ + 63 < k;     // SI <= SJ: both column groups are real assets
     // GRAM rows: [intraday rows, padded to whole chunks][daily rows]; a chunk is purely one kind
     const int hchunks = (mm + CH - 1) / CH;
     const int nchunks = (MODE == MODE_GRAM) ? hchunks + (nr + CH - 1) / CH : SB / CH;
@@ -211,18 +212,31 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
             const int cnt = hf ? mm : nr;
             rowv = r < cnt;
             const int rc = rowv ? r : cnt - 1;
-            const double* base;
-            if (hf) {
-                const long long row = hridx ? (long long)hridx[rc] : hfirst + rc;
-                base = A.hf_panel + row * (long long)A.hf_ld;
-                rowc = zc[rc];
-            } else {
-                const long long row = dridx ? (long long)dridx[rc] : dfirst + rc;
-                base = A.panel + row * (long long)A.panel_ld;
-                rowc = rf ? rf[rc] : 0.0;
-            }
+            const int* ridx = hf ? hridx : dridx;
+            const bool o32 = ((hf ? A.hf_off32 : A.panel_off32) & (ridx ? 1 : 2)) != 0;
+            if (hf) rowc = zc[rc];
+            else rowc = rf ? rf[rc] : 0.0;
+            if (o32) {
+                // one 32-bit offset per row on a uniform base (scalar registers) + the lane's column offsets:
+                // vector instructions are what this kernel runs out of (see posterior_fused_impl.h, staging)
+                const int ld = hf ? A.hf_ld : A.panel_ld;
+                const double* pb = hf ? A.hf_panel : A.panel;
+                const char* ub = (const char*)(ridx ? pb : pb + (hf ? hfirst : dfirst) * (long long)ld);
+                const unsigned ro = __umul24(ridx ? (unsigned)ridx[rc] : (unsigned)rc, (unsigned)ld * 8u);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = base[pcol[i]];
+                for (int i = 0; i < 8; ++i) v[i] = *(const double*)(ub + (size_t)(ro + 8u * (unsigned)pcol[i]));
+            } else {
+                const double* base;
+                if (hf) {
+                    const long long row = hridx ? (long long)hridx[rc] : hfirst + rc;
+                    base = A.hf_panel + row * (long long)A.hf_ld;
+                } else {
+                    const long long row = dridx ? (long long)dridx[rc] : dfirst + rc;
+                    base = A.panel + row * (long long)A.panel_ld;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = base[pcol[i]];
+            }
         } else {
             const int r = ch * CH + srow;
             const double* rowA = (MODE == MODE_TRSM) ? rinv + r * SB : M + (long long)(64 * j + r) * KP;
@@ -236,12 +250,26 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
     auto store = [&](double* buf, int ch) {
         if (MODE == MODE_GRAM) {
             const bool hf = ch < hchunks;
+            const bool ragged = ((hf ? ch : ch - hchunks) + 1) * CH > (hf ? mm : nr);   // uniform
+            if (interior) {
+                // every column of this super-tile pair is a real asset: no column selects at all
+                if (hf) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                double x;
-                if (hf) x = cval[i] ? sqs * (v[i] - yb[i]) : (cbord[i] ? rowc : 0.0);   // sqrt(s) (y - ybar) | c sqrt(s) z_r
-                else x = cval[i] ? v[i] - rowc : (cbord[i] ? 1.0 : 0.0);                // x - rf (ref:57) | 1
-                v[i] = rowv ? x : 0.0;
+                    for (int i = 0; i < 8; ++i) v[i] = sqs * (v[i] - yb[i]);            // sqrt(s) (y - ybar)
+                } else if (rf) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] -= rowc;                           // x - rf (ref:57)
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (hf) v[i] = cval[i] ? sqs * (v[i] - yb[i]) : (cbord[i] ? rowc : 0.0);   // ... | c sqrt(s) z_r
+                    else v[i] = cval[i] ? v[i] - rowc : (cbord[i] ? 1.0 : 0.0);                // ... | 1
+                }
+            }
+            if (ragged) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = rowv ? v[i] : 0.0;
             }
         }
 #pragma unroll
