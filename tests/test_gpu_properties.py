@@ -1,0 +1,124 @@
+"""Size-independent properties of the HIP path at BASELINE.json's FULL shapes (configs[1] at its 10,000
+windows; the k=500 / k=1000 shapes at a window count that fits a test).  The oracle cannot be run at these
+sizes in seconds, so the checks are properties the domain offers:
+
+* round trip: the downloaded posterior matrix S1 times the solution reproduces the right-hand side;
+* determinism / idempotence: a second run of the same batch is bit-identical;
+* window independence: a window's result does not depend on the batch around it (bit-identical when
+  the batch is reversed, cut in two shards, or reduced to a sample) - what makes sharding exact;
+* scale law: doubling the risk aversion halves the weights exactly (ref:836 divides by gamma last);
+* equivariance: permuting the assets (col_idx) permutes the weights (summation order changes: 1e-10);
+* a sampled oracle check on windows drawn from the full batch.
+-m gpu."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from incorporating_different_sources_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # config id, windows
+    (2, 10_000),       # BASELINE configs[1] as benchmarked: k=100, N=250, 10k windows (register-tile kernel)
+    (3, 512),          # configs[2] shape k=500, N=250, m=389 (tiled path)
+    (5, 48),           # configs[4] shape k=1000, N=500, m=1715 (tiled path)
+]
+
+
+@pytest.fixture(scope="module")
+def native():
+    from incorporating_different_sources_amd import _native
+    return _native
+
+
+def _inputs(cfg, W):
+    shp = synthetic.config_shapes(cfg)
+    inp = synthetic.make_kernel_inputs(shp["k"], shp["N"], W, seed=shp["seed"], hf_days=shp["hf_days"])
+    kw = dict(panel=inp["panel"], start=inp["start"], hf_panel=inp["hf_panel"], hf_start=inp["hf_start"],
+              w0=inp["w0"], n0=inp["n0"])
+    return shp, inp, kw
+
+
+def _run(native, shp, W, kw, gamma=5.0, strategy="conjugate", **extra):
+    wts, status, aux = native.posterior_batch(strategy, shp["k"], shp["N"], gamma, n_r=shp["n_r"],
+                                              m=shp["m"] if strategy == "conjugate" else 0, **kw, **extra)
+    assert wts.shape == (W, shp["k"])
+    return wts, status, aux
+
+
+@pytest.mark.parametrize("cfg,W", SHAPES)
+def test_full_size_properties(native, cfg, W):
+    shp, inp, kw = _inputs(cfg, W)
+    k, N = shp["k"], shp["N"]
+    wts, status, aux = _run(native, shp, W, kw)
+    assert (status == 0).all() and np.isfinite(wts).all()
+
+    # determinism / idempotence
+    again, s2, a2 = _run(native, shp, W, kw)
+    assert np.array_equal(again, wts) and np.array_equal(a2, aux)
+
+    # scale law: gamma -> 2 gamma halves the weights exactly
+    half, _, _ = _run(native, shp, W, kw, gamma=10.0)
+    assert np.array_equal(half * 2.0, wts)
+
+    # window independence: reversed batch, two shards, a sample - all bit-identical per window
+    rev = {key: (val[::-1].copy() if key in ("start", "hf_start", "w0", "n0") else val) for key, val in kw.items()}
+    wrev, _, _ = _run(native, shp, W, rev)
+    assert np.array_equal(wrev[::-1], wts)
+    cut = W // 2 + 1
+    for lo, hi in ((0, cut), (cut, W)):
+        part = {key: (val[lo:hi] if key in ("start", "hf_start", "w0", "n0") else val) for key, val in kw.items()}
+        wpart, _, _ = _run(native, shp, hi - lo, part)
+        assert np.array_equal(wpart, wts[lo:hi])
+
+    # round trip S1 w1 = c S0 w0 + t on sampled windows (fused kernel: matrix read-back; ref:489)
+    rng = np.random.default_rng(cfg)
+    sample = np.unique(np.concatenate([[0, W - 1], rng.integers(0, W, 6)]))
+    if k <= 239:
+        dev = native.default_device()
+        b = native.Batch(dev, "conjugate", k, N, shp["n_r"], 5.0, W, shp["m"])
+        try:
+            b.upload(**kw)
+            b.run()
+            for w in sample:
+                S1, rhs = b.download_matrix(int(w), "posterior")
+                n1, q1 = aux[w, 1], aux[w, 4]
+                w1 = wts[w] * 5.0 * (n1 - q1) / (n1 + k + 2)                      # undo ref:572-575, 836
+                resid = S1 @ w1 - rhs
+                assert np.abs(resid).max() <= 1e-11 * max(1.0, np.abs(S1).max() * np.abs(w1).max() * k)
+                assert abs(w1 @ rhs - q1) <= 1e-10 * max(1.0, abs(q1))           # q1 = w1'S1 w1 (ref:574)
+        finally:
+            b.close()
+
+    # sampled oracle check on windows of the full batch
+    sub = {key: (val[sample] if key in ("start", "hf_start", "w0", "n0") else val) for key, val in kw.items()}
+    ref, rstat, raux = oracle.posterior_batch_c("conjugate", k, N, 5.0, n_r=shp["n_r"], m=shp["m"], **sub)
+    np.testing.assert_allclose(wts[sample], ref, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(aux[sample, :6], raux[:, :6], rtol=1e-9, atol=1e-12)
+
+
+def test_asset_permutation_equivariance_full_size(native):
+    """Permuting the assets of every window permutes its weights (configs[1], 10,000 windows)."""
+    shp, inp, kw = _inputs(2, 10_000)
+    k, W = shp["k"], 10_000
+    base, _, _ = _run(native, shp, W, kw)
+    rng = np.random.default_rng(7)
+    perm = np.stack([rng.permutation(k) for _ in range(W)]).astype(np.int32)
+    kwp = dict(kw, col_idx=perm, w0=np.take_along_axis(kw["w0"], perm, axis=1))
+    got, status, _ = _run(native, shp, W, kwp)
+    assert (status == 0).all()
+    np.testing.assert_allclose(got, np.take_along_axis(base, perm, axis=1), rtol=0, atol=1e-10)
+
+
+def test_jeffreys_solution_is_linear_in_the_right_hand_side_full_size(native):
+    """(T - t t'/N)^-1 (a r1 + r2) = a (..)^-1 r1 + (..)^-1 r2 over the full configs[1] batch."""
+    shp, inp, kw = _inputs(2, 10_000)
+    k, W = shp["k"], 10_000
+    jk = dict(panel=kw["panel"], start=kw["start"])
+    rng = np.random.default_rng(11)
+    r1, r2 = rng.normal(size=(W, k)), rng.normal(size=(W, k))
+    x1, _, _ = _run(native, shp, W, jk, gamma=1.0, strategy="jeffreys", rhs=r1)
+    x2, _, _ = _run(native, shp, W, jk, gamma=1.0, strategy="jeffreys", rhs=r2)
+    x3, _, _ = _run(native, shp, W, jk, gamma=1.0, strategy="jeffreys", rhs=3.0 * r1 + r2)
+    scale = np.abs(x3).max()
+    np.testing.assert_allclose(x3, 3.0 * x1 + x2, rtol=0, atol=1e-10 * scale)
