@@ -329,8 +329,10 @@ __global__ void __launch_bounds__(NTHREADS) tiled_rank1_kernel(const tp_kargs_t 
 // last block only: border row and padding) behave as identity rows.
 __global__ void __launch_bounds__(NTHREADS) tiled_diag_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws, const int j) {
     constexpr int LD = SB + 1;
-    __shared__ double Ab[SB * LD];
-    __shared__ double Rv[SB * LD];
+    constexpr int LT = SB / 2 + 1;
+    __shared__ double Ab[SB * LD];             // working block; row p turns into R[p][:] one pivot after it is used
+    __shared__ double Rv[SB * LD];             // R^-1
+    __shared__ double Tm[(SB / 2) * LT];       // product scratch of the blocked inverse (75 KB in all: 2 blocks per CU)
     __shared__ int bad;
     const int tid = threadIdx.x;
     const long long wl = blockIdx.x;
@@ -341,46 +343,78 @@ __global__ void __launch_bounds__(NTHREADS) tiled_diag_kernel(const tp_kargs_t A
     for (int e = tid; e < SB * SB; e += NTHREADS) {
         const int i = e >> 6, c = e & 63;
         Ab[i * LD + c] = M[(long long)(64 * j + i) * KP + 64 * j + c];
+        Rv[i * LD + c] = 0.0;
     }
     __syncthreads();
+    // Right-looking Cholesky with ONE barrier per pivot: row p is not rescaled while others read it - the
+    // trailing update scales its two factors on the fly (same products, same rounding as updating from a
+    // rescaled row), and the scaled row is written back one pivot later, when nobody reads row p any more.
+    // Thread (g, c): column c, rows p+1+g, p+5+g, ... - the row is wave-uniform, so Ab[p][i] is an LDS broadcast.
+    const int c = tid & 63, g = tid >> 6;
+    double prev = 0.0;                          // R[p-1][c], held by wave 0
     for (int p = 0; p < npiv; ++p) {
         const double d = Ab[p * LD + p];
         if (!(d > 0.0) && tid == 0) bad = 1;
         const double rinv = 1.0 / sqrt(d);
-        __syncthreads();                       // everyone has read d before row p is rescaled
-        if (tid >= p && tid < SB) Ab[p * LD + tid] *= rinv;
-        __syncthreads();
-        // trailing update of rows p+1 .. npiv-1, all columns c >= i (the border column included)
-        const int nrow = npiv - 1 - p;
-        for (int e = tid; e < nrow * SB; e += NTHREADS) {
-            const int i = p + 1 + e / SB, c = e % SB;
-            if (c >= i) Ab[i * LD + c] = fma(-Ab[p * LD + i], Ab[p * LD + c], Ab[i * LD + c]);
-        }
+        const double sc = Ab[p * LD + c] * rinv;                     // R[p][c]
+        if (g == 0 && p > 0) Ab[(p - 1) * LD + c] = prev;
+        prev = (c >= p) ? sc : 0.0;                                  // all 64 columns: the border column rides along
+        for (int i = p + 1 + g; i < npiv; i += 4)
+            if (c >= i) Ab[i * LD + c] = fma(-(Ab[p * LD + i] * rinv), sc, Ab[i * LD + c]);
         __syncthreads();
     }
-    // R_jj^-1 (upper): thread c solves column c by back substitution; rows >= npiv are identity rows
+    if (g == 0 && npiv > 0) Ab[(npiv - 1) * LD + c] = prev;
+    __syncthreads();
+    // factored rows back to the arena (upper part; the border column of the last block is y), then the matrix
+    // that is inverted: blockdiag(R[0:npiv, 0:npiv], I) - rows >= npiv (border row, padding) are identity rows
+    // and the columns >= npiv of the real rows do not take part.
+    for (int e = tid; e < SB * SB; e += NTHREADS) {
+        const int i = e >> 6, cc = e & 63;
+        if (i < npiv && cc >= i) M[(long long)(64 * j + i) * KP + 64 * j + cc] = Ab[i * LD + cc];
+        if (i >= npiv) Ab[i * LD + cc] = (i == cc) ? 1.0 : 0.0;
+        else if (cc >= npiv) Ab[i * LD + cc] = 0.0;
+    }
+    __syncthreads();
+    // R^-1 by blocks: the four 16 x 16 diagonal blocks by back substitution (16 threads each, one column per
+    // thread), then [[A, B], [0, C]]^-1 = [[A^-1, -A^-1 B C^-1], [0, C^-1]] at the 32- and the 64-level with
+    // all 256 threads on the products: the dependent chain is ~450 operations instead of ~2000.
     if (tid < SB) {
-        const int c = tid;
-        for (int i = SB - 1; i >= 0; --i) {
-            double x;
-            if (i > c) x = 0.0;
-            else if (i >= npiv) x = (i == c) ? 1.0 : 0.0;
-            else {
-                double s = (i == c) ? 1.0 : 0.0;
-                const int lim = (c < npiv - 1) ? c : npiv - 1;
-                for (int q = i + 1; q <= lim; ++q) s = fma(-Ab[i * LD + q], Rv[q * LD + c], s);
-                x = s / Ab[i * LD + i];
+        const int b0 = 16 * (tid >> 4), cc = tid & 15;
+        for (int i = 15; i >= 0; --i) {
+            double x = 0.0;
+            if (i <= cc) {
+                double sum = (i == cc) ? 1.0 : 0.0;
+                for (int q = i + 1; q <= cc; ++q) sum = fma(-Ab[(b0 + i) * LD + b0 + q], Rv[(b0 + q) * LD + b0 + cc], sum);
+                x = sum / Ab[(b0 + i) * LD + b0 + i];
             }
-            Rv[i * LD + c] = x;
+            Rv[(b0 + i) * LD + b0 + cc] = x;
         }
     }
     __syncthreads();
-    double* rinv = ws.rinv + (wl * ws.NSB + j) * (long long)(SB * SB);
+#pragma unroll
+    for (int h = 16; h <= 32; h *= 2) {                 // half-size of the blocks being joined
+        const int npairs = SB / (2 * h);                // 2 pairs of 16-blocks, then 1 pair of 32-blocks
+        // T = B C^-1   (B = R[r0 : r0+h, r0+h : r0+2h], C^-1 = Rv of the lower-right block, upper triangular)
+        for (int e = tid; e < npairs * h * h; e += NTHREADS) {
+            const int pr = e / (h * h), i = (e / h) % h, cc = e % h, r0 = 2 * h * pr;
+            double sum = 0.0;
+            for (int q = 0; q <= cc; ++q) sum = fma(Ab[(r0 + i) * LD + r0 + h + q], Rv[(r0 + h + q) * LD + r0 + h + cc], sum);
+            Tm[(h * pr + i) * LT + cc] = sum;
+        }
+        __syncthreads();
+        // X = -A^-1 T
+        for (int e = tid; e < npairs * h * h; e += NTHREADS) {
+            const int pr = e / (h * h), i = (e / h) % h, cc = e % h, r0 = 2 * h * pr;
+            double sum = 0.0;
+            for (int q = i; q < h; ++q) sum = fma(Rv[(r0 + i) * LD + r0 + q], Tm[(h * pr + q) * LT + cc], sum);
+            Rv[(r0 + i) * LD + r0 + h + cc] = -sum;
+        }
+        __syncthreads();
+    }
+    double* rinvp = ws.rinv + (wl * ws.NSB + j) * (long long)(SB * SB);
     for (int e = tid; e < SB * SB; e += NTHREADS) {
-        const int i = e >> 6, c = e & 63;
-        rinv[e] = Rv[i * LD + c];
-        // factored rows back to the arena (upper part; the border column of the last block is y)
-        if (i < npiv && c >= i) M[(long long)(64 * j + i) * KP + 64 * j + c] = Ab[i * LD + c];
+        const int i = e >> 6, cc = e & 63;
+        rinvp[e] = Rv[i * LD + cc];
     }
     if (tid == 0 && bad) ws.flags[wl] = 1;
 }
