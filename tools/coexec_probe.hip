@@ -71,9 +71,10 @@ __device__ __forceinline__ double run_role(int role, int iters) {
         default: return 0.0;
     }
 }
-__global__ void __launch_bounds__(512) probe(double* out, long long* cyc, int roleA, int roleB, int iters) {
+__global__ void __launch_bounds__(512) probe(double* out, long long* cyc, int roleA, int roleB, int iters, int prioB) {
     const int wv = threadIdx.x >> 6;
     const int role = wv < 4 ? roleA : roleB;
+    if (wv >= 4 && prioB) __builtin_amdgcn_s_setprio(3);
     __syncthreads();
     const long long c0 = clock64();
     const double s = run_role(role, iters);
@@ -87,10 +88,13 @@ int main() {
     const char* names[] = {"idle", "mfma_f64", "fma_f64", "readlane+fma_f64", "fma_f32"};
     const int per_iter[] = {0, 8, 8, 24, 8};
     const int iters = 4000;
+    for (int prio = 0; prio <= 1; ++prio)
     for (int a = 1; a <= 4; ++a)
         for (int b = 0; b <= 4; ++b) {
-            probe<<<1, 512>>>(out, cyc, a, b, iters);   // warm
-            probe<<<1, 512>>>(out, cyc, a, b, iters);
+            if (prio && !(a == 1 && b >= 2)) continue;   // priority runs: vector roles against the MFMA stream only
+            if (prio) printf("[role B at s_setprio 3] ");
+            probe<<<1, 512>>>(out, cyc, a, b, iters, prio);   // warm
+            probe<<<1, 512>>>(out, cyc, a, b, iters, prio);
             CK(hipDeviceSynchronize());
             long long h[8];
             CK(hipMemcpy(h, cyc, sizeof h, hipMemcpyDeviceToHost));
