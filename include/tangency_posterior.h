@@ -97,6 +97,19 @@ typedef struct tp_inputs {
     const int32_t* hf_count;   /* optional [W] intraday returns actually used (<= m, >= 2) */
     const double* w0;          /* [W x k] prior weights, ref:361-380 */
     const double* n0;          /* [W] prior strength, ref:247-267 */
+    /* Optional price front-end (ref:31-62, 136-161, 299-314).  With `ret_num` given, `panel` holds PRICES
+     * [panel_rows x panel_ld] and the library forms the log-return panel on the device,
+     *     R[i][c] = log(P[ret_num[i]][c] / P[ret_den[i]][c])   for i < ret_rows   (NaN -> 0, +-inf -> +-DBL_MAX),
+     * e.g. (i, i-1) for daily returns, (bin end, previous bin end) for weekly / monthly resampled windows and
+     * (date, last complete bin end) for the running bin.  start / row_idx then address rows of R (and are
+     * checked against ret_rows).  `hf_ret_num` does the same for the intraday panel.  Zero-initialise the
+     * struct to leave the front-end off: the panels are then log-returns, as above. */
+    const int32_t* ret_num;    /* optional [ret_rows] price row in the numerator */
+    const int32_t* ret_den;    /* [ret_rows] price row in the denominator (required with ret_num) */
+    int64_t ret_rows;
+    const int32_t* hf_ret_num; /* optional [hf_ret_rows] */
+    const int32_t* hf_ret_den;
+    int64_t hf_ret_rows;
 } tp_inputs_t;
 
 const char* tp_version(void);
@@ -112,6 +125,13 @@ int tp_destroy(tp_handle_t h);
 const char* tp_last_error(tp_handle_t h); /* h may be NULL: last error of a failed tp_create */
 int tp_device_info(tp_handle_t h, char* name, int name_len, int* compute_units, int* clock_mhz,
                    int64_t* hbm_bytes);
+
+/* The price front-end on its own: out[i][c] = log(prices[num[i]][c] / prices[den[i]][c]) for i < n_out, c < ld
+ * (NaN -> 0, +-inf -> +-DBL_MAX), host buffers in and out.  Replaces the np.log(prices / prices.shift(1)) of
+ * ref:44 (daily or resampled prices) and ref:311 (intraday bars); tp_batch_upload runs the same kernel when
+ * tp_inputs_t.ret_num is set, without the copy back. */
+int tp_log_returns(tp_handle_t h, const double* prices, int64_t price_rows, int32_t ld, const int32_t* num,
+                   const int32_t* den, int64_t n_out, double* out /* [n_out x ld] */);
 
 /* A batch is W windows resident in HBM: inputs uploaded once, run any number of times.
  * Replaces the per-date loop body of Portfolio.update_portfolio -> calculate_portfolio_weights

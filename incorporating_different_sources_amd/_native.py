@@ -32,7 +32,7 @@ UNIQUE_ID_BYTES = 128
 # every symbol include/tangency_posterior.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTS = [
     "tp_version", "tp_max_assets", "tp_device_count", "tp_create", "tp_destroy", "tp_last_error", "tp_device_info",
-    "tp_batch_create", "tp_batch_upload", "tp_batch_set_rhs", "tp_batch_set_shift", "tp_batch_download_rhs", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1", "tp_batch_download_matrix", "tp_batch_debug_stamps",
+    "tp_log_returns", "tp_batch_create", "tp_batch_upload", "tp_batch_set_rhs", "tp_batch_set_shift", "tp_batch_download_rhs", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1", "tp_batch_download_matrix", "tp_batch_debug_stamps",
     "tp_batch_destroy", "tp_posterior_batch", "tp_synchronize", "tp_last_timing", "tp_region_begin",
     "tp_region_end", "tp_last_launch", "tp_comm_unique_id", "tp_comm_init", "tp_comm_destroy",
     "tp_batch_gather", "tp_batch_gather_async", "tp_batch_download_gathered",
@@ -56,7 +56,9 @@ class tp_inputs_t(ctypes.Structure):
                 ("col_idx", POINTER(c_int32)), ("rf_adj", POINTER(c_double)),
                 ("hf_panel", POINTER(c_double)), ("hf_rows", c_int64),
                 ("hf_start", POINTER(c_int64)), ("hf_row_idx", POINTER(c_int32)), ("hf_count", POINTER(c_int32)),
-                ("w0", POINTER(c_double)), ("n0", POINTER(c_double))]
+                ("w0", POINTER(c_double)), ("n0", POINTER(c_double)),
+                ("ret_num", POINTER(c_int32)), ("ret_den", POINTER(c_int32)), ("ret_rows", c_int64),
+                ("hf_ret_num", POINTER(c_int32)), ("hf_ret_den", POINTER(c_int32)), ("hf_ret_rows", c_int64)]
 
 
 def _load():
@@ -72,6 +74,8 @@ def _load():
     lib.tp_create.argtypes = [c_int, POINTER(c_void_p)]
     lib.tp_destroy.argtypes = [c_void_p]
     lib.tp_device_info.argtypes = [c_void_p, c_char_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int64)]
+    lib.tp_log_returns.argtypes = [c_void_p, POINTER(c_double), c_int64, c_int32, POINTER(c_int32), POINTER(c_int32),
+                                   c_int64, POINTER(c_double)]
     lib.tp_batch_create.argtypes = [c_void_p, POINTER(tp_params_t), c_int64, POINTER(c_void_p)]
     lib.tp_batch_upload.argtypes = [c_void_p, POINTER(tp_inputs_t)]
     lib.tp_batch_set_rhs.argtypes = [c_void_p, POINTER(c_double)]
@@ -202,6 +206,20 @@ class Device:
     def comm_destroy(self):
         self._check(lib.tp_comm_destroy(self._h))
 
+    # ---- price front-end ----------------------------------------------------------------------
+    def log_returns(self, prices, num, den) -> np.ndarray:
+        """out[i] = log(prices[num[i]] / prices[den[i]]) on the device (NaN -> 0), ref:44 / ref:311."""
+        P = _arr(prices, np.float64)
+        if P.ndim != 2:
+            raise ValueError("prices must be 2-D [rows x assets]")
+        num, den = _arr(num, np.int32), _arr(den, np.int32)
+        if num.ndim != 1 or num.shape != den.shape:
+            raise ValueError("num / den: two equally long 1-D index arrays expected")
+        out = np.empty((num.size, P.shape[1]), dtype=np.float64)
+        self._check(lib.tp_log_returns(self._h, _ptr(P, c_double), P.shape[0], P.shape[1], _ptr(num, c_int32),
+                                       _ptr(den, c_int32), num.size, _ptr(out, c_double)))
+        return out
+
     # ---- batches ------------------------------------------------------------------------------
     def batch(self, strategy, k, N, n_r, gamma, W, m=0, flags=0) -> "Batch":
         return Batch(self, strategy, k, N, n_r, gamma, W, m, flags)
@@ -231,7 +249,10 @@ class Batch:
             pass
 
     def upload(self, panel, start=None, hf_panel=None, hf_start=None, w0=None, n0=None, row_idx=None,
-               n_rows=None, col_idx=None, rf_adj=None, hf_row_idx=None, hf_count=None):
+               n_rows=None, col_idx=None, rf_adj=None, hf_row_idx=None, hf_count=None, ret_pairs=None,
+               hf_ret_pairs=None):
+        """H2D.  `ret_pairs=(num, den)`: `panel` holds PRICES and the device forms the log-return panel
+        R[i] = log(P[num[i]] / P[den[i]]) that start / row_idx address; `hf_ret_pairs` likewise for `hf_panel`."""
         W, k, n_r, m = self.W, self.k, self.n_r, self.m
         panel = _arr(panel, np.float64)
         if panel.ndim != 2:
@@ -248,6 +269,12 @@ class Batch:
             hf_row_idx=_arr(hf_row_idx, np.int32, (W, m), "hf_row_idx"),
             hf_count=_arr(hf_count, np.int32, (W,), "hf_count"),
             w0=_arr(w0, np.float64, (W, k), "w0"), n0=_arr(n0, np.float64, (W,), "n0"))
+        for name, pairs in (("ret", ret_pairs), ("hf_ret", hf_ret_pairs)):
+            num = _arr(pairs[0], np.int32) if pairs is not None else None
+            den = _arr(pairs[1], np.int32) if pairs is not None else None
+            if pairs is not None and (num.ndim != 1 or num.shape != den.shape or num.size < 1):
+                raise ValueError(f"{name}_pairs: two equally long 1-D index arrays expected")
+            a[name + "_num"], a[name + "_den"] = num, den
         inp = tp_inputs_t(
             _ptr(a["panel"], c_double), panel.shape[0], panel.shape[1],
             hf_panel.shape[1] if hf_panel is not None else 0,
@@ -255,7 +282,10 @@ class Batch:
             _ptr(a["col_idx"], c_int32), _ptr(a["rf_adj"], c_double),
             _ptr(a["hf_panel"], c_double), hf_panel.shape[0] if hf_panel is not None else 0,
             _ptr(a["hf_start"], c_int64), _ptr(a["hf_row_idx"], c_int32), _ptr(a["hf_count"], c_int32),
-            _ptr(a["w0"], c_double), _ptr(a["n0"], c_double))
+            _ptr(a["w0"], c_double), _ptr(a["n0"], c_double),
+            _ptr(a["ret_num"], c_int32), _ptr(a["ret_den"], c_int32), a["ret_num"].size if a["ret_num"] is not None else 0,
+            _ptr(a["hf_ret_num"], c_int32), _ptr(a["hf_ret_den"], c_int32),
+            a["hf_ret_num"].size if a["hf_ret_num"] is not None else 0)
         self._keep = a     # host arrays stay alive for the duration of the (synchronous) upload
         self.dev._check(lib.tp_batch_upload(self._b, ctypes.byref(inp)))
         self._keep = None
@@ -353,7 +383,7 @@ def default_device() -> Device:
 def posterior_batch(strategy, k, N, gamma, panel, start=None, n_r=None, hf_panel=None, hf_start=None, m=0,
                     w0=None, n0=None, row_idx=None, n_rows=None, col_idx=None, rf_adj=None,
                     hf_row_idx=None, hf_count=None, device: Device | None = None, want_aux=True, rhs=None, flags=0,
-                    shift=None):
+                    shift=None, ret_pairs=None, hf_ret_pairs=None):
     """Upload + run + download.  Same argument meaning as `oracle.posterior_batch` (tests compare them)."""
     dev = device or default_device()
     W = len(start) if start is not None else len(row_idx)
@@ -364,7 +394,8 @@ def posterior_batch(strategy, k, N, gamma, panel, start=None, n_r=None, hf_panel
         if shift is not None:
             b.set_shift(shift)
         b.upload(panel, start=start, hf_panel=hf_panel, hf_start=hf_start, w0=w0, n0=n0, row_idx=row_idx,
-                 n_rows=n_rows, col_idx=col_idx, rf_adj=rf_adj, hf_row_idx=hf_row_idx, hf_count=hf_count)
+                 n_rows=n_rows, col_idx=col_idx, rf_adj=rf_adj, hf_row_idx=hf_row_idx, hf_count=hf_count,
+                 ret_pairs=ret_pairs, hf_ret_pairs=hf_ret_pairs)
         b.run()
         return b.download(want_aux=want_aux)
     finally:

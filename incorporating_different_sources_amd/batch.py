@@ -8,10 +8,12 @@ log-returns twice per window, ref:299-314 intraday filter, ref:90-114 MCM window
 converted once per `market_data` into numpy panels (`MarketPanels`); a date then costs a few
 `searchsorted` calls and small index arithmetic, and the O(n k) values never leave the shared panels:
 
-* daily panel      `L[i] = log(P[i] / P[i-1])` (or the resampled weekly / monthly equivalent plus one
-                   "tail" row per date for the running bin, ref:149-156)
-* intraday panel   `H[i] = log(p[i] / p[i-1])` over consecutive bars
-* per window       row indices into the panels, the k column indices in market-cap order, the per-row
+* daily panel      PRICES (daily, or the weekly / monthly `resample().last()` bins plus one price row per date
+                   for the running bin, ref:149-156) and the row pairs (numerator, denominator) of every
+                   log-return row `L[i] = log(P[num_i] / P[den_i])`: the device forms the return panel
+                   (`tp_inputs_t.ret_num`); the host only keeps WHICH returns are NaN
+* intraday panel   bar prices and the pairs (i, i-1), likewise
+* per window       row indices into the return panels, the k column indices in market-cap order, the per-row
                    risk-free adjustment (ref:40-57), prior weights w0 and strength n0
 
 `tests/test_host_batch_packing.py` holds this packer to the frame-based one
@@ -41,6 +43,14 @@ def _resample_last(df, frequency):
         return df.resample(_RESAMPLE_RULE[frequency]).last()
     except ValueError:  # pandas < 2.2
         return df.resample("M" if frequency == "monthly" else "W").last()
+
+
+def _return_is_nan(num, den):
+    """Where log(num / den) would be NaN (a missing price, or a ratio that is negative or 0/0): the host only
+    needs the mask (ref:60 dropna, ref:646 eligibility); the logarithm itself is taken on the device."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = num / den
+    return np.isnan(ratio) | (ratio < 0)
 
 
 class MarketPanels:
@@ -75,32 +85,29 @@ class MarketPanels:
         self.hf_has = np.array([t in hf.columns for t in self.tickers])
         self.hf_ns = _ns(hf.index)
         Hp = hf.reindex(columns=self.tickers).to_numpy(dtype=np.float64)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            H = np.full_like(Hp, np.nan)
-            if len(Hp) > 1:
-                H[1:] = np.log(Hp[1:] / Hp[:-1])              # H[i]: return from bar i-1 to bar i
-        self.H = np.ascontiguousarray(H)
+        self.Hp = np.ascontiguousarray(Hp)                     # bar prices; return i = bar i-1 -> bar i (device)
+        self.H_nan = np.ones(Hp.shape, dtype=bool)
+        if len(Hp) > 1:
+            self.H_nan[1:] = _return_is_nan(Hp[1:], Hp[:-1])
         self.hf_notna_cum = np.concatenate([np.zeros((1, K), np.int32), np.cumsum(~np.isnan(Hp), axis=0, dtype=np.int32)])
 
         rf = market_data["risk_free_rate_df"]
         self.rf_ns = _ns(rf.index)
         self.rf = rf.to_numpy(dtype=np.float64).reshape(len(rf), -1)[:, 0]
 
-        with np.errstate(divide="ignore", invalid="ignore"):
-            if frequency == "daily":
-                L = np.full_like(self.P, np.nan)
-                L[1:] = np.log(self.P[1:] / self.P[:-1])      # L[i]: return from date i-1 to date i
-                self.L = np.ascontiguousarray(L)
-                self.label_ns = self.date_ns
-            else:
-                R = _resample_last(prices, frequency)          # complete bins are the same for every date
-                self.R = R.to_numpy(dtype=np.float64)
-                self.label_ns = _ns(R.index)
-                L = np.full_like(self.R, np.nan)
-                L[1:] = np.log(self.R[1:] / self.R[:-1])
-                self.L = np.ascontiguousarray(L)
-                # bin of each trading date: first label >= date (labels are bin ends)
-                self.bin_of = np.searchsorted(self.label_ns, self.date_ns, side="left")
+        if frequency == "daily":
+            self.base = self.P                                 # price rows the return rows are formed from
+            self.label_ns = self.date_ns
+        else:
+            R = _resample_last(prices, frequency)              # complete bins are the same for every date
+            self.R = np.ascontiguousarray(R.to_numpy(dtype=np.float64))
+            self.base = self.R
+            self.label_ns = _ns(R.index)
+            # bin of each trading date: first label >= date (labels are bin ends)
+            self.bin_of = np.searchsorted(self.label_ns, self.date_ns, side="left")
+        self.L_nan = np.ones(self.base.shape, dtype=bool)      # return row i: base row i-1 -> base row i
+        if len(self.base) > 1:
+            self.L_nan[1:] = _return_is_nan(self.base[1:], self.base[:-1])
         self._mcm = {}
 
     # -- market-condition metric (ref:90-114, 247-267) --------------------------------------------
@@ -181,11 +188,11 @@ def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None):
     row_idx = np.zeros((W, n_r_max), dtype=np.int32)
     n_rows = np.zeros(W, dtype=np.int32)
     rf_adj = np.zeros((W, n_r_max), dtype=np.float64)
-    tails = []                                           # extra panel rows (running-bin returns), resampled windows
+    tails = []                                           # extra price rows (date prices of running bins) + their denominators
     w0 = np.zeros((W, k)) if conj else None
     n0 = np.zeros(W) if conj else None
     hf_rows, hf_count = [], np.zeros(W, dtype=np.int32)
-    base_rows = mp.L.shape[0]
+    base_rows = mp.base.shape[0]
     mcm = mp.mcm(market_data, "vix_prices_df" if "_vix_" in strategy else "epu_prices_df") if conj else None
     all_members = np.ones(K, dtype=bool)
 
@@ -220,12 +227,11 @@ def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None):
             b = int(mp.bin_of[pos])
             first_bin = max(0, b - N + 1)
             body = np.arange(first_bin + 1, b, dtype=np.int64)                 # returns between complete bins
-            with np.errstate(divide="ignore", invalid="ignore"):
-                prev = mp.R[b - 1] if b >= 1 else np.full(K, np.nan)
-                tail = np.log(mp.P[pos] / prev) if b > first_bin else None     # running bin: last price is P(date)
+            # running bin: its return is P(date) over the last complete bin (a price row of its own for the device)
+            tail_nan = _return_is_nan(mp.P[pos], mp.R[b - 1]) if b > first_bin else None
             rows = body
-            if tail is not None:
-                tails.append(tail)
+            if tail_nan is not None:
+                tails.append((pos, b - 1))
                 rows = np.concatenate([body, [base_rows + len(tails) - 1]])
             lab = mp.label_ns[first_bin:b + 1]
         if len(lab) >= 2:
@@ -237,10 +243,12 @@ def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None):
             raise AssertionError("Unexpected large gap between return dates.")
         # dropna (ref:60): a NaN risk-free value or a NaN return of a selected asset drops the row
         if freq == "daily":
-            vals_nan = np.isnan(mp.L[rows][:, cols]).any(axis=1)
+            vals_nan = mp.L_nan[rows][:, cols].any(axis=1)
         else:
-            block = np.vstack([mp.L[body][:, cols], tail[cols][None, :]]) if tail is not None else mp.L[body][:, cols]
-            vals_nan = np.isnan(block).any(axis=1)
+            block = mp.L_nan[body][:, cols]
+            if tail_nan is not None:
+                block = np.vstack([block, tail_nan[cols][None, :]])
+            vals_nan = block.any(axis=1)
         keep = ~vals_nan & ~np.isnan(adj)
         rows, adj = rows[keep], adj[keep]
         n_rows[w] = len(rows)
@@ -256,7 +264,7 @@ def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None):
             e = int(np.searchsorted(mp.hf_ns, min(d + _NS_PER_DAY, end_of_day), side="right"))
             cand = np.arange(a + 1, e, dtype=np.int64)                          # the first bar's return is NaN (shift)
             if len(cand):
-                cand = cand[~np.isnan(mp.H[cand][:, cols]).any(axis=1)]
+                cand = cand[~mp.H_nan[cand][:, cols].any(axis=1)]
             hf_rows.append(cand)
             hf_count[w] = len(cand)
             # ---- prior weights and strength
@@ -268,8 +276,14 @@ def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None):
 
     if (n_rows < 1).any():
         raise ValueError("a rolling window has no usable return rows")
-    panel = mp.L if not tails else np.vstack([mp.L, np.asarray(tails)])
-    kw = dict(panel=np.nan_to_num(panel, nan=0.0), start=None, n_r=int(n_rows.max()),
+    # Price panel + the (numerator, denominator) rows of every return row; the device takes the logarithms.
+    # Return row i < base_rows is base row i over base row i-1 (row 0: itself, a zero row nobody selects); the
+    # running-bin rows follow, each the date's price row (appended below the bins) over its last complete bin.
+    nb = base_rows
+    ret_num = np.arange(nb + len(tails), dtype=np.int32)
+    ret_den = np.concatenate([[0], np.arange(nb - 1), [t[1] for t in tails]]).astype(np.int32)
+    panel = mp.base if not tails else np.vstack([mp.base, mp.P[[t[0] for t in tails]]])
+    kw = dict(panel=panel, ret_pairs=(ret_num, ret_den), start=None, n_r=int(n_rows.max()),
               row_idx=np.ascontiguousarray(row_idx[:, :int(n_rows.max())]), n_rows=n_rows, col_idx=col_idx,
               rf_adj=np.ascontiguousarray(rf_adj[:, :int(n_rows.max())]))
     if conj:
@@ -279,8 +293,9 @@ def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None):
         hidx = np.zeros((W, m), dtype=np.int32)
         for w, r in enumerate(hf_rows):
             hidx[w, :len(r)] = r
-        kw.update(hf_panel=np.nan_to_num(mp.H, nan=0.0), hf_start=None, hf_row_idx=hidx, hf_count=hf_count, m=m,
-                  w0=w0, n0=n0)
+        nh = mp.Hp.shape[0]
+        kw.update(hf_panel=mp.Hp, hf_ret_pairs=(np.arange(nh, dtype=np.int32), np.maximum(np.arange(nh) - 1, 0).astype(np.int32)),
+                  hf_start=None, hf_row_idx=hidx, hf_count=hf_count, m=m, w0=w0, n0=n0)
     return kw, labels
 
 

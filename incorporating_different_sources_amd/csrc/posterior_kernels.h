@@ -63,3 +63,7 @@ struct tp_tiled_ws_t {
 int tp_tiled_max_assets(void);
 void tp_tiled_geometry(int k, int* KP, int* NS, int* NSB);
 hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStream_t stream);
+
+// price front-end (returns_frontend.hip): out[i][c] = log(prices[num[i]][c] / prices[den[i]][c]), NaN -> 0
+hipError_t tp_log_return_rows_launch(const double* prices, int ld, const int* num, const int* den, long long n_out,
+                                     double* out, hipStream_t stream);

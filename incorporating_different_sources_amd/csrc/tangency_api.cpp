@@ -176,9 +176,32 @@ tp_kargs_t make_kargs(tp_batch_t b) {
 
 // Host-side validation of every index the kernel will dereference: a bad offset must never reach
 // the device (an out-of-bounds access can take the whole node down).
-int validate_inputs(tp_handle_t h, const tp_params_t& p, int64_t W, const tp_inputs_t* in) {
-    if (!in) return fail(h, TP_ERR_INVALID, "inputs is NULL");
-    if (!in->panel || in->panel_rows < 1 || in->panel_ld < 1) return fail(h, TP_ERR_INVALID, "panel missing");
+// price front-end: every (numerator, denominator) row must lie inside the price panel
+int validate_pairs(tp_handle_t h, const char* what, const int32_t* num, const int32_t* den, int64_t n, int64_t price_rows) {
+    if (!num) return TP_OK;
+    if (!den) return fail(h, TP_ERR_INVALID, "%s_num without %s_den", what, what);
+    if (n < 1 || n > 0x7fffffffLL) return fail(h, TP_ERR_INVALID, "%s_rows=%lld out of range", what, (long long)n);
+    for (int64_t i = 0; i < n; ++i)
+        if (num[i] < 0 || num[i] >= price_rows || den[i] < 0 || den[i] >= price_rows)
+            return fail(h, TP_ERR_INVALID, "%s pair %lld = (%d, %d) outside the price panel (%lld rows)", what,
+                        (long long)i, num[i], den[i], (long long)price_rows);
+    return TP_OK;
+}
+
+int validate_inputs(tp_handle_t h, const tp_params_t& p, int64_t W, const tp_inputs_t* in_raw) {
+    if (!in_raw) return fail(h, TP_ERR_INVALID, "inputs is NULL");
+    if (!in_raw->panel || in_raw->panel_rows < 1 || in_raw->panel_ld < 1) return fail(h, TP_ERR_INVALID, "panel missing");
+    int rcp = validate_pairs(h, "ret", in_raw->ret_num, in_raw->ret_den, in_raw->ret_rows, in_raw->panel_rows);
+    if (rcp != TP_OK) return rcp;
+    if (p.strategy == TP_STRATEGY_CONJUGATE && in_raw->hf_panel) {
+        rcp = validate_pairs(h, "hf_ret", in_raw->hf_ret_num, in_raw->hf_ret_den, in_raw->hf_ret_rows, in_raw->hf_rows);
+        if (rcp != TP_OK) return rcp;
+    }
+    // with the price front-end the windows address rows of the RETURN panel
+    tp_inputs_t eff = *in_raw;
+    if (eff.ret_num) eff.panel_rows = eff.ret_rows;
+    if (eff.hf_ret_num) eff.hf_rows = eff.hf_ret_rows;
+    const tp_inputs_t* in = &eff;
     if (!in->start && !in->row_idx) return fail(h, TP_ERR_INVALID, "need start[] or row_idx[]");
     const bool conj = p.strategy == TP_STRATEGY_CONJUGATE;
     if (conj) {
@@ -359,6 +382,36 @@ int tp_device_info(tp_handle_t h, char* name, int name_len, int* compute_units, 
     return TP_OK;
 }
 
+int tp_log_returns(tp_handle_t h, const double* prices, int64_t price_rows, int32_t ld, const int32_t* num,
+                   const int32_t* den, int64_t n_out, double* out) {
+    if (!h) return TP_ERR_INVALID;
+    if (!prices || !out || price_rows < 1 || ld < 1) return fail(h, TP_ERR_INVALID, "tp_log_returns: prices / out missing");
+    if (!num) return fail(h, TP_ERR_INVALID, "tp_log_returns: num missing");
+    int rc = validate_pairs(h, "ret", num, den, n_out, price_rows);
+    if (rc != TP_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    DevBuf dp, dn, dd, dout;
+    rc = put(h, dp, prices, sizeof(double) * (size_t)price_rows * ld);
+    if (rc == TP_OK) rc = put(h, dn, num, sizeof(int32_t) * (size_t)n_out);
+    if (rc == TP_OK) rc = put(h, dd, den, sizeof(int32_t) * (size_t)n_out);
+    if (rc == TP_OK) rc = ensure(h, dout, sizeof(double) * (size_t)n_out * ld);
+    if (rc == TP_OK) {
+        HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+        hipError_t e = tp_log_return_rows_launch((const double*)dp.p, ld, (const int*)dn.p, (const int*)dd.p,
+                                                 (long long)n_out, (double*)dout.p, h->stream);
+        if (e != hipSuccess) rc = fail(h, TP_ERR_HIP, "log-return kernel launch failed: %s", hipGetErrorString(e));
+    }
+    if (rc == TP_OK) {
+        HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+        h->kernel_timed = true;                          // tp_last_timing().kernel_ms = this kernel
+        HIP_TRY(h, hipMemcpyAsync(out, dout.p, sizeof(double) * (size_t)n_out * ld, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        rc = harvest_kernel_time(h);
+    }
+    release(dp); release(dn); release(dd); release(dout);
+    return rc;
+}
+
 int tp_batch_create(tp_handle_t h, const tp_params_t* p, int64_t W, tp_batch_t* out) {
     if (!h || !out) return TP_ERR_INVALID;
     *out = nullptr;
@@ -404,14 +457,32 @@ int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in) {
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     h->kernel_timed = false;
 #define PUT(buf, ptr, bytes) do { rc = put(h, b->buf, (ptr), (bytes)); if (rc != TP_OK) return rc; } while (0)
-    PUT(panel, in->panel, sizeof(double) * (size_t)in->panel_rows * in->panel_ld);
+    // panels: log-returns as given, or formed on the device from prices (returns_frontend.hip)
+    DevBuf prices, pnum, pden;
+    auto panel_in = [&](DevBuf& dst, const double* src, int64_t rows, int ld, const int32_t* num, const int32_t* den,
+                        int64_t n_out) -> int {
+        if (!num) return put(h, dst, src, sizeof(double) * (size_t)rows * ld);
+        int r = put(h, prices, src, sizeof(double) * (size_t)rows * ld);
+        if (r == TP_OK) r = put(h, pnum, num, sizeof(int32_t) * (size_t)n_out);
+        if (r == TP_OK) r = put(h, pden, den, sizeof(int32_t) * (size_t)n_out);
+        if (r == TP_OK) r = ensure(h, dst, sizeof(double) * (size_t)n_out * ld);
+        if (r != TP_OK) return r;
+        hipError_t e = tp_log_return_rows_launch((const double*)prices.p, ld, (const int*)pnum.p, (const int*)pden.p,
+                                                 (long long)n_out, (double*)dst.p, h->stream);
+        if (e != hipSuccess) return fail(h, TP_ERR_HIP, "log-return kernel launch failed: %s", hipGetErrorString(e));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));      // the staging buffers are reused / freed next
+        return TP_OK;
+    };
+    rc = panel_in(b->panel, in->panel, in->panel_rows, in->panel_ld, in->ret_num, in->ret_den, in->ret_rows);
+    if (rc != TP_OK) { release(prices); release(pnum); release(pden); return rc; }
     PUT(start, in->start, sizeof(int64_t) * (size_t)W);
     PUT(row_idx, in->row_idx, sizeof(int32_t) * (size_t)W * p.n_r);
     PUT(n_rows, in->n_rows, sizeof(int32_t) * (size_t)W);
     PUT(col_idx, in->col_idx, sizeof(int32_t) * (size_t)W * p.k);
     PUT(rf_adj, in->rf_adj, sizeof(double) * (size_t)W * p.n_r);
     if (conj) {
-        PUT(hf_panel, in->hf_panel, sizeof(double) * (size_t)in->hf_rows * in->hf_ld);
+        rc = panel_in(b->hf_panel, in->hf_panel, in->hf_rows, in->hf_ld, in->hf_ret_num, in->hf_ret_den, in->hf_ret_rows);
+        if (rc != TP_OK) { release(prices); release(pnum); release(pden); return rc; }
         PUT(hf_start, in->hf_start, sizeof(int64_t) * (size_t)W);
         PUT(hf_row_idx, in->hf_row_idx, sizeof(int32_t) * (size_t)W * p.m);
         PUT(hf_count, in->hf_count, sizeof(int32_t) * (size_t)W);
@@ -419,6 +490,7 @@ int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in) {
         PUT(n0, in->n0, sizeof(double) * (size_t)W);
     }
 #undef PUT
+    release(prices); release(pnum); release(pden);
     b->panel_ld = in->panel_ld;
     b->hf_ld = conj ? in->hf_ld : 0;
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));

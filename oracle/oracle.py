@@ -216,11 +216,19 @@ def greyserman_window(X, gamma, xi, eta):
     return (acc / len(xi))[:, 0]
 
 
+def log_return_rows(prices, num, den):
+    """ref:44 / ref:311 for arbitrary row pairs: log(P[num] / P[den]), then the packer's nan_to_num(nan=0)."""
+    P = np.asarray(prices, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        return np.nan_to_num(np.log(P[np.asarray(num)] / P[np.asarray(den)]), nan=0.0)
+
+
 # ----------------------------------------------------------------------------------------------
 # batched driver over the panel+offset layout of include/tangency_posterior.h (numpy loop; small cases)
 def posterior_batch(strategy, k, N, gamma, panel, start, n_r, hf_panel=None, hf_start=None, m=None,
                     w0=None, n0=None, row_idx=None, n_rows=None, col_idx=None, rf_adj=None,
-                    hf_row_idx=None, hf_count=None, rhs=None, center_rows=False, no_center=False, shift=None):
+                    hf_row_idx=None, hf_count=None, rhs=None, center_rows=False, no_center=False, shift=None,
+                    ret_pairs=None, hf_ret_pairs=None):
     """Loop `conjugate_window` / `jeffreys_window` over W windows described the way the C-ABI takes them.
 
     Returns (weights [W x k], status [W] int32, aux [W x 8] = n0, n1, c, q0, q1, denom, 0, 0).
@@ -229,6 +237,10 @@ def posterior_batch(strategy, k, N, gamma, panel, start, n_r, hf_panel=None, hf_
     weights = np.empty((W, k))
     status = np.zeros(W, dtype=np.int32)
     aux = np.zeros((W, 8))
+    if ret_pairs is not None:           # price front-end of the C-ABI (tp_inputs_t.ret_num / ret_den)
+        panel = log_return_rows(panel, *ret_pairs)
+    if hf_ret_pairs is not None:
+        hf_panel = log_return_rows(hf_panel, *hf_ret_pairs)
     for w in range(W):
         nr = int(n_rows[w]) if n_rows is not None else n_r
         rows = (np.asarray(row_idx[w][:nr], dtype=np.int64) if row_idx is not None

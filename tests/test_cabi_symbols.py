@@ -31,12 +31,27 @@ def test_library_exports_every_declared_symbol():
     assert lib.tp_max_assets() >= 100
 
 
-def test_struct_layout_matches_header():
+def test_struct_layout_matches_header(tmp_path):
+    """ctypes mirrors of the two C structs against the header itself: gcc compiles a probe that prints
+    sizeof / offsetof of every field."""
+    import subprocess
     from incorporating_different_sources_amd import _native
-    # tp_params_t: 6 x int32 + double; tp_inputs_t: 11 pointers + 2 x int64 + 2 x int32
-    assert ctypes.sizeof(_native.tp_params_t) == 32
-    assert ctypes.sizeof(_native.tp_inputs_t) == 8 + 8 + 4 + 4 + 5 * 8 + 8 + 8 + 5 * 8
-    assert _native.tp_inputs_t.hf_ld.offset == 20 and _native.tp_inputs_t.start.offset == 24
+    probe = tmp_path / "layout.c"
+    fields_p = [f[0] for f in _native.tp_params_t._fields_]
+    fields_i = [f[0] for f in _native.tp_inputs_t._fields_]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "tangency_posterior.h"', 'int main(void) {',
+             'printf("%zu %zu\\n", sizeof(tp_params_t), sizeof(tp_inputs_t));']
+    lines += [f'printf("%zu\\n", offsetof(tp_params_t, {f}));' for f in fields_p]
+    lines += [f'printf("%zu\\n", offsetof(tp_inputs_t, {f}));' for f in fields_i]
+    lines += ['return 0; }']
+    probe.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), str(probe), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert [int(out[0]), int(out[1])] == [ctypes.sizeof(_native.tp_params_t), ctypes.sizeof(_native.tp_inputs_t)]
+    offs = [int(x) for x in out[2:]]
+    mine = [getattr(_native.tp_params_t, f).offset for f in fields_p] + [getattr(_native.tp_inputs_t, f).offset for f in fields_i]
+    assert offs == mine
 
 
 @pytest.mark.skipif(have_gpu(), reason="CPU-only behaviour")

@@ -280,3 +280,48 @@ def test_shift_is_rejected_where_it_does_not_apply(native):
     with pytest.raises(Exception, match=">= 0"):
         b.set_shift(np.array([[1.0, -1.0], [0.0, 0.0]]))
     b.close()
+
+
+def test_log_return_kernel_matches_numpy(native):
+    """F4: the price front-end on its own (tp_log_returns) against numpy's log on the same row pairs, NaN /
+    zero / negative prices included.  Both logarithms are within an ulp of the true value, not bit-equal."""
+    rng = np.random.default_rng(42)
+    rows, cols = 700, 133
+    P = 100.0 * np.exp(np.cumsum(rng.normal(3e-4, 0.01, size=(rows, cols)), axis=0))
+    P[5, 7] = np.nan; P[100:110, 0] = np.nan; P[300, 3] = 0.0; P[301, 4] = -1.0
+    num = np.concatenate([np.arange(rows), rng.integers(0, rows, 500)]).astype(np.int32)
+    den = np.concatenate([np.maximum(np.arange(rows) - 1, 0), rng.integers(0, rows, 500)]).astype(np.int32)
+    got = native.default_device().log_returns(P, num, den)
+    ref = oracle.log_return_rows(P, num, den)
+    assert got.shape == ref.shape == (rows + 500, cols)
+    assert np.array_equal(got == 0.0, ref == 0.0)                 # NaN -> 0 in the same places; exact zeros (p/p)
+    assert np.array_equal(np.abs(got) > 1e300, np.abs(ref) > 1e300)   # +-inf -> +-DBL_MAX in the same places
+    fin = np.abs(ref) < 1e300
+    np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-15, atol=1e-18)
+    with pytest.raises(Exception, match="outside the price panel"):
+        native.default_device().log_returns(P, np.array([rows], np.int32), np.array([0], np.int32))
+
+
+@pytest.mark.parametrize("k,N", [(10, 60), (100, 250), (300, 400)])
+def test_price_front_end_matches_return_panels(native, k, N):
+    """F4: prices + (numerator, denominator) rows into tp_batch_upload give the weights of the same windows
+    fed as log-return panels (fused and tiled path), and the oracle's."""
+    W = 6
+    hf_days = 1 if k < 240 else 5
+    inp = synthetic.make_kernel_inputs(k, N, W, seed=660000 + k, hf_days=hf_days)
+    # prices whose consecutive log-returns are the synthetic panels (up to the rounding of exp / log)
+    P = 100.0 * np.exp(np.concatenate([np.zeros((1, k)), np.cumsum(inp["panel"], axis=0)]))
+    H = 50.0 * np.exp(np.concatenate([np.zeros((1, k)), np.cumsum(inp["hf_panel"], axis=0)]))
+    pairs = lambda n: (np.arange(1, n, dtype=np.int32), np.arange(0, n - 1, dtype=np.int32))   # return row i: price i+1 / i
+    common = dict(start=inp["start"], n_r=inp["n_r"], hf_start=inp["hf_start"], m=inp["m"], w0=inp["w0"], n0=inp["n0"])
+    got, status, aux = native.posterior_batch("conjugate", k, N, 5.0, panel=P, hf_panel=H, ret_pairs=pairs(len(P)),
+                                              hf_ret_pairs=pairs(len(H)), **common)
+    assert (status == 0).all()
+    Lp, Lh = oracle.log_return_rows(P, *pairs(len(P))), oracle.log_return_rows(H, *pairs(len(H)))
+    same, _, _ = native.posterior_batch("conjugate", k, N, 5.0, panel=Lp, hf_panel=Lh, **common)
+    np.testing.assert_allclose(got, same, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(same).max()))
+    ref, _, _ = oracle.posterior_batch_c("conjugate", k, N, 5.0, panel=Lp, hf_panel=Lh, **common)
+    np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(ref).max()))
+    with pytest.raises(Exception, match="outside the panel"):      # windows are checked against the RETURN rows
+        native.posterior_batch("conjugate", k, N, 5.0, panel=P, hf_panel=H, ret_pairs=(pairs(len(P))[0][:-3], pairs(len(P))[1][:-3]),
+                               hf_ret_pairs=pairs(len(H)), **common)

@@ -1,10 +1,13 @@
 """F1 (batch-native host packing) against the frame-based packer, which mirrors the reference's
-per-date DataFrame slicing line by line.  No GPU needed: only the packed arrays are compared."""
+per-date DataFrame slicing line by line.  No GPU needed: only the packed arrays are compared.  The packer
+hands PRICE panels plus (numerator, denominator) row pairs to the device (F4); here the oracle's numpy
+restatement of that front-end (`oracle.log_return_rows`) stands in for the device kernel."""
 import numpy as np
 import pandas as pd
 import pytest
 
 from incorporating_different_sources_amd import batch, synthetic
+from oracle import oracle
 
 
 @pytest.fixture(scope="module")
@@ -43,17 +46,20 @@ def test_batch_packer_equals_frame_packer(pc, case, strat):
     dates = pc.rebalancing_schedule([pd.Timestamp(d) for d in days[start_idx:]], rebal)
     kw, labels = batch.pack_windows(dates, spec, md)
     conj = strat.startswith("conjugate")
+    ret_panel = oracle.log_return_rows(kw["panel"], *kw["ret_pairs"])
+    hf_ret_panel = oracle.log_return_rows(kw["hf_panel"], *kw["hf_ret_pairs"]) if conj else None
+    assert kw["row_idx"].max() < len(ret_panel)
     for w, d in enumerate(dates):
         item = pc._pack_window(d, spec, md)                      # reference-style slicing for this date
         assert labels[w] == item["labels"]
         nr = kw["n_rows"][w]
-        Xb = kw["panel"][kw["row_idx"][w, :nr]][:, kw["col_idx"][w]]
+        Xb = ret_panel[kw["row_idx"][w, :nr]][:, kw["col_idx"][w]]
         assert Xb.shape == item["X"].shape
         np.testing.assert_array_equal(Xb, item["X"])
         np.testing.assert_allclose(kw["rf_adj"][w, :nr], item["rf"], rtol=1e-15, atol=0)
         if conj:
             m = kw["hf_count"][w]
-            Yb = kw["hf_panel"][kw["hf_row_idx"][w, :m]][:, kw["col_idx"][w]]
+            Yb = hf_ret_panel[kw["hf_row_idx"][w, :m]][:, kw["col_idx"][w]]
             np.testing.assert_array_equal(Yb, item["Y"])
             np.testing.assert_allclose(kw["w0"][w], item["w0"], rtol=1e-15)
             np.testing.assert_allclose(kw["n0"][w], item["n0"], rtol=1e-14)
