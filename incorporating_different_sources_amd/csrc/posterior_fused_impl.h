@@ -528,7 +528,10 @@ __device__ __forceinline__ void gram_phase(const RowSource& src, const int* __re
 }
 
 
-template <int NT, int NW, int FIX>
+// LEAN: the batch is in the contiguous layout (no row / column index arrays, 32-bit offsets) - a kernel of its
+// own, chosen on the host, so that neither staging variant's registers weigh on the other's allocation (one
+// kernel carrying both spilled the staged values INSIDE the generic chunk loop: 2.06 instead of 1.43 ms).
+template <int NT, int NW, int FIX, bool LEAN>
 __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, const int tid0, const int wv) {
     using C = Cfg<NT, NW>;
 // lane constants of one phase: tid, lane, MFMA fragment column fr and row group fq, border-column masks
@@ -644,7 +647,7 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
             acc[decltype(sc_)::value] = d4{0.0, 0.0, 0.0, 0.0};
         });
         // ---- phase B: centred intraday Gram
-        if (!cols && !hs.ridx && hs.off32) gram_phase_lean<C, true, FIX>(hs, k, lds, tid0, wv, acc);
+        if constexpr (LEAN) gram_phase_lean<C, true, FIX>(hs, k, lds, tid0, wv, acc);
         else gram_phase<C, true, FIX>(hs, cols, k, lds, tid0, wv, acc, nullptr);
         TP_MARK(2);
         // ---- phase C: q0, c, scaling (ref:333, 415-418)
@@ -702,7 +705,7 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
         ds.sub_row = A.rf_adj ? A.rf_adj + w * (long long)A.n_r : nullptr;
         ds.count = A.n_rows ? A.n_rows[w] : A.n_r;
         ds.off32 = (A.panel_off32 & (ds.ridx ? 1 : 2)) != 0;
-        if (!cols && !ds.ridx && ds.off32) gram_phase_lean<C, false, FIX>(ds, k, lds, tid0, wv, acc);
+        if constexpr (LEAN) gram_phase_lean<C, false, FIX>(ds, k, lds, tid0, wv, acc);
         else gram_phase<C, false, FIX>(ds, cols, k, lds, tid0, wv, acc, TP_LOOPSTAMP_PTR);
     }
 
@@ -1057,40 +1060,53 @@ constexpr int tp_min_waves_for_tiles(int nt) {
 #define TP_WAVE_SPECIALISE 1
 #endif
 
-template <int NT, int NW>
+template <int NT, int NW, bool LEAN>
 __global__ void __launch_bounds__(64 * NW, tp_min_waves_for_tiles(NT)) posterior_fused_kernel(const tp_kargs_t A) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #if TP_WAVE_SPECIALISE
     wave_dispatch<NW>(wv, [&](auto wc) __attribute__((always_inline)) {
-        window_body<NT, NW, decltype(wc)::value>(A, lds, tid, decltype(wc)::value);
+        window_body<NT, NW, decltype(wc)::value, LEAN>(A, lds, tid, decltype(wc)::value);
     });
 #else
-    window_body<NT, NW, -1>(A, lds, tid, wv);
+    window_body<NT, NW, -1, LEAN>(A, lds, tid, wv);
 #endif
 }
 
-template <int NT, int NW>
-hipError_t launch_one(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info) {
+// the contiguous layout the LEAN kernel is built for: no index arrays, window-relative 32-bit offsets
+inline bool tp_layout_is_lean(const tp_kargs_t& a) {
+    if (a.col_idx || a.row_idx || !(a.panel_off32 & 2)) return false;
+    if (a.strategy == 0 && (a.hf_row_idx || !(a.hf_off32 & 2))) return false;
+    return true;
+}
+
+template <int NT, int NW, bool LEAN>
+hipError_t launch_variant(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info) {
     using C = Cfg<NT, NW>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)posterior_fused_kernel<NT, NW>,
+        hipError_t e = hipFuncSetAttribute((const void*)posterior_fused_kernel<NT, NW, LEAN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     if (info) { info->grid = grid; info->block = C::NTHREADS; info->lds_bytes = C::LDS_BYTES; info->ntile = NT; }
-    hipLaunchKernelGGL((posterior_fused_kernel<NT, NW>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((posterior_fused_kernel<NT, NW, LEAN>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, stream, a);
     return hipGetLastError();
+}
+
+template <int NT, int NW>
+hipError_t launch_one(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info) {
+    return tp_layout_is_lean(a) ? launch_variant<NT, NW, true>(a, grid, stream, info)
+                                : launch_variant<NT, NW, false>(a, grid, stream, info);
 }
 
 template <int NT, int NW>
 int blocks_per_cu() {
     using C = Cfg<NT, NW>;
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)posterior_fused_kernel<NT, NW>, C::NTHREADS,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)posterior_fused_kernel<NT, NW, true>, C::NTHREADS,
                                                      C::LDS_BYTES) != hipSuccess || n < 1)
         n = 1;
     return n;
