@@ -170,9 +170,11 @@ def select_universe(mp: MarketPanels, pos, size, window_days, rebal_frequency, m
     return order.astype(np.int32), caps[order]
 
 
-def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None):
+def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None, return_caps=False):
     """All rebalancing dates of one spec -> keyword arguments of `_native.posterior_batch` plus the
-    per-window ticker labels.  Raises the reference's exceptions for the reference's conditions."""
+    per-window ticker labels (and, with `return_caps`, the market caps [W x k] of the selected assets in the
+    same order: the value-weighted comparison portfolio of ref:1077-1104).  Raises the reference's exceptions
+    for the reference's conditions."""
     strategy = portfolio_spec["weighting_strategy"]
     freq = portfolio_spec["rolling_window_frequency"]
     N, k = portfolio_spec["rolling_window"], portfolio_spec["size"]
@@ -184,6 +186,7 @@ def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None):
     n_r_max = N - 1
 
     col_idx = np.zeros((W, k), dtype=np.int32)
+    caps_all = np.zeros((W, k), dtype=np.float64)
     labels = []
     row_idx = np.zeros((W, n_r_max), dtype=np.int32)
     n_rows = np.zeros(W, dtype=np.int32)
@@ -211,6 +214,7 @@ def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None):
         if len(cols) != k:
             raise ValueError(f"universe has {len(cols)} assets, portfolio_spec['size'] is {k}")
         col_idx[w] = cols
+        caps_all[w] = caps
         labels.append([mp.tickers[c] for c in cols])
         # ref:986-988: the filtered prices of the window must be complete
         lo_row = max(0, pos + 1 - window_days)
@@ -296,6 +300,8 @@ def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None):
         nh = mp.Hp.shape[0]
         kw.update(hf_panel=mp.Hp, hf_ret_pairs=(np.arange(nh, dtype=np.int32), np.maximum(np.arange(nh) - 1, 0).astype(np.int32)),
                   hf_start=None, hf_row_idx=hidx, hf_count=hf_count, m=m, w0=w0, n0=n0)
+    if return_caps:
+        return kw, labels, caps_all
     return kw, labels
 
 

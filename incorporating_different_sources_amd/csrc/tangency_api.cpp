@@ -164,7 +164,8 @@ tp_kargs_t make_kargs(tp_batch_t b) {
         const size_t rows = bytes / ((size_t)ld * 8);
         int f = 0;
         if (bytes < (1ull << 32) && rows < (1u << 24)) f |= 1;
-        if ((size_t)rows_per_window * ld * 8 < (1ull << 32) && (size_t)rows_per_window < (1u << 24)) f |= 2;
+        // + 64: the lean loop advances its row offset one chunk past the window before it is clamped
+        if (((size_t)rows_per_window + 64) * ld * 8 < (1ull << 32) && (size_t)rows_per_window < (1u << 24)) f |= 2;
         return f;
     };
     a.panel_off32 = off32(b->panel.bytes, b->panel_ld, b->p.n_r);

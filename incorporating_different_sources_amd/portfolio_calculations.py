@@ -694,6 +694,36 @@ def _pack_window(trading_date_ts, portfolio_spec, market_data):
     return item
 
 
+def _weights_for_dates(trading_dates, portfolio_spec, market_data):
+    """(weights [W x k], labels, column indices [W x k], market caps [W x k]) for MANY rebalancing dates: one
+    host pass (`batch.pack_windows`) and, for the estimators, one device batch."""
+    strategy = portfolio_spec["weighting_strategy"]
+    if strategy in _OUT_OF_SCOPE:
+        _not_in_scope(f"calculate_{strategy}_portfolio")()
+    if strategy not in _CONJUGATE and strategy not in ("jeffreys", "jorion", "greyserman", "vw", "ew"):
+        logger.error("Unknown weights spec.")
+        raise ValueError("Unknown weights spec.")
+    members_of = _members_provider(market_data)
+    kw, labels, caps = batch.pack_windows(list(trading_dates), portfolio_spec, market_data, members_of=members_of,
+                                          return_caps=True)
+    cols = kw["col_idx"]
+    k, N, gamma = portfolio_spec["size"], portfolio_spec["rolling_window"], portfolio_spec.get("risk_aversion")
+    if strategy == "vw":
+        weights = caps / caps.sum(axis=1, keepdims=True)                 # ref:692-695 (already cap-descending)
+    elif strategy == "ew":
+        weights = np.full(caps.shape, 1 / k)                             # ref:670-672
+    elif strategy == "jorion":
+        kw.pop("start", None)
+        weights = _jorion_batch(kw, gamma, k, N)
+    elif strategy == "greyserman":
+        weights = _greyserman_batch(kw, gamma, k, N)
+    else:
+        conj = strategy in _CONJUGATE
+        weights, status, aux = _native.posterior_batch("conjugate" if conj else "jeffreys", k, N, gamma, **kw)
+        _raise_on_status(status)
+    return weights, labels, cols, caps
+
+
 def calculate_portfolio_weights_batch(trading_dates, portfolio_spec, market_data):
     """Weights for MANY rebalancing dates with one device call (the batch-native form of ref:941).
 
@@ -702,27 +732,11 @@ def calculate_portfolio_weights_batch(trading_dates, portfolio_spec, market_data
     strategy = portfolio_spec["weighting_strategy"]
     if strategy in ("vw", "ew"):
         return [calculate_portfolio_weights(d, portfolio_spec, market_data) for d in trading_dates]
-    if strategy in _OUT_OF_SCOPE:
-        _not_in_scope(f"calculate_{strategy}_portfolio")()
-    if strategy not in _CONJUGATE and strategy not in ("jeffreys", "jorion", "greyserman"):
-        logger.error("Unknown weights spec.")
-        raise ValueError("Unknown weights spec.")
     if not trading_dates:
+        if strategy in _OUT_OF_SCOPE:
+            _not_in_scope(f"calculate_{strategy}_portfolio")()
         return []
-    members_of = _members_provider(market_data)
-    kw, labels = batch.pack_windows(list(trading_dates), portfolio_spec, market_data, members_of=members_of)
-    if strategy == "jorion":
-        kw.pop("start", None)
-        weights = _jorion_batch(kw, portfolio_spec["risk_aversion"], portfolio_spec["size"], portfolio_spec["rolling_window"])
-        return [pd.DataFrame({"Weight": weights[i]}, index=pd.Index(labels[i], name="Stock")) for i in range(len(labels))]
-    if strategy == "greyserman":
-        weights = _greyserman_batch(kw, portfolio_spec["risk_aversion"], portfolio_spec["size"], portfolio_spec["rolling_window"])
-        return [pd.DataFrame({"Weight": weights[i]}, index=pd.Index(labels[i], name="Stock")) for i in range(len(labels))]
-    conj = strategy in _CONJUGATE
-    weights, status, aux = _native.posterior_batch("conjugate" if conj else "jeffreys", portfolio_spec["size"],
-                                                   portfolio_spec["rolling_window"], portfolio_spec["risk_aversion"],
-                                                   **kw)
-    _raise_on_status(status)
+    weights, labels, _, _ = _weights_for_dates(trading_dates, portfolio_spec, market_data)
     return [pd.DataFrame({"Weight": weights[i]}, index=pd.Index(labels[i], name="Stock")) for i in range(len(labels))]
 
 
@@ -870,19 +884,87 @@ class Portfolio:
         self.last_rebalance_date_ts = trading_date_ts
 
 
+def _rf_asof(risk_free_rate_df, trading_dates):
+    """`risk_free_rate_df.asof(ts).iloc[0]` for every date (ref:1139): the last row at or before ts that has no
+    NaN (DataFrame.asof skips NaN rows)."""
+    rf = risk_free_rate_df.sort_index()
+    vals = rf.to_numpy(dtype=np.float64).reshape(len(rf), -1)
+    ok = ~np.isnan(vals).any(axis=1)
+    idx_ns = rf.index.values.astype("datetime64[ns]").astype(np.int64)[ok]
+    first = vals[ok][:, 0]
+    d = np.array([pd.Timestamp(ts).value for ts in trading_dates], dtype=np.int64)
+    pos = np.searchsorted(idx_ns, d, side="right") - 1
+    return np.where(pos >= 0, first[np.maximum(pos, 0)], np.nan)
+
+
+def _replay_backtest(trading_dates, rebalance_dates, weights, cols, caps, tickers, portfolio_spec, market_data):
+    """The daily loop of ref:1127-1219 (mark to market, drift, rebalance, turnover ref:1054-1075, weight metrics,
+    distance to the value-weighted portfolio ref:1077-1104) over plain arrays: the weights of every rebalancing
+    date are already in hand, so a day costs a few k-vector operations instead of a dozen DataFrame slices.
+    Same operations in the same order as `Portfolio.update_portfolio`, NaN-skipping sums where pandas skips."""
+    name = portfolio_spec["display_name"]
+    K = len(tickers)
+    sr = market_data["stock_simple_returns_df"]
+    missing = [ts for ts in trading_dates[1:] if ts not in sr.index]
+    if missing:
+        raise KeyError(missing[0])                                        # ref:1134 `.loc[trading_date_ts]`
+    S = sr.reindex(index=pd.DatetimeIndex(trading_dates), columns=tickers).to_numpy(dtype=np.float64)
+    rf_daily_all = (_rf_asof(market_data["risk_free_rate_df"], trading_dates) + 1) ** (1 / 252) - 1     # ref:1140
+    scaling = portfolio_spec["risk_aversion"] if portfolio_spec.get("risk_aversion") is not None else 1
+    cost = portfolio_spec["turnover_cost"]
+    reb_index = {ts: j for j, ts in enumerate(rebalance_dates)}
+    n_days = len(trading_dates)
+    returns = np.full(n_days, np.nan)
+    turnover = np.full(len(rebalance_dates), np.nan)
+    metrics = np.full((len(rebalance_dates), 5), np.nan)
+    w = held = None
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for di, ts in enumerate(trading_dates):
+            if di > 0:
+                r, rf_daily = S[di, held], rf_daily_all[di]
+                cash = 1 - np.nansum(w)
+                returns[di] = np.nansum(r * w) + cash * rf_daily                    # ref:1137-1145
+                cash_after = cash * (1 + rf_daily)
+                drifted = w * (1 + r)
+                total = np.nansum(drifted) + cash_after
+                w = drifted / total                                                 # ref:1152-1159
+                if abs((w.sum() + cash_after / total) - 1) > 1e-5:
+                    logger.error("Weights do not sum to 1.")
+                    raise ValueError("Weights do not sum to 1.")
+            j = reb_index.get(ts)
+            if j is None:
+                continue
+            before_w, before_held = w, held
+            w, held = weights[j].astype(np.float64, copy=True), cols[j]
+            vw = caps[j] / np.nansum(caps[j])                                       # ref:692-695
+            pos_w, neg_w = w[w > 0], w[w < 0]
+            metrics[j] = (pos_w.max() if pos_w.size else np.nan, neg_w.min() if neg_w.size else np.nan,
+                          pos_w.mean() if pos_w.size else np.nan, neg_w.mean() if neg_w.size else np.nan,
+                          np.nanmean(np.abs(w * scaling - vw)))                      # ref:1100-1104
+            if before_w is not None:
+                dense_b, dense_a = np.zeros(K), np.zeros(K)                         # outer merge + fillna(0), ref:1062-1066
+                dense_b[before_held] = np.nan_to_num(before_w, nan=0.0)
+                dense_a[held] = np.nan_to_num(w, nan=0.0)
+                union = np.union1d(before_held, held)
+                traded = np.abs(dense_b[union] - dense_a[union]).sum()
+                turnover[j] = (traded + abs(np.nansum(before_w) - np.nansum(w))) / 2    # ref:1068-1075
+                returns[di] -= cost / 10000 * turnover[j]                           # ref:1212
+    days = pd.DatetimeIndex(trading_dates)
+    reb = pd.DatetimeIndex(rebalance_dates)
+    return {"portfolio_simple_returns_series": pd.Series(returns[1:], index=days[1:], name=name, dtype="float64"),
+            "portfolio_turnover_series": pd.Series(turnover[1:], index=reb[1:], name=name, dtype="float64"),
+            "portfolio_weights_metrics_df": pd.DataFrame(
+                metrics, index=reb, dtype="float64",
+                columns=["max_long", "max_short", "avg_long", "avg_short", "average_distance_to_comparison_portfolio"])}
+
+
 def backtest_portfolio(portfolio_spec, ts_start_date, ts_end_date, market_data):
-    """Same inputs and outputs as ref:1221-1238; all posterior solves happen in one device batch."""
+    """Same inputs and outputs as ref:1221-1238.  All posterior solves of the backtest happen in ONE device
+    batch, and the daily replay runs over arrays (`_replay_backtest`); `Portfolio.update_portfolio` remains the
+    day-at-a-time form of the same loop."""
     trading_dates = [pd.Timestamp(ts) for ts in market_data["stock_prices_df"].index]
     trading_dates = [ts for ts in trading_dates if ts_start_date <= ts <= ts_end_date]
-    strategy = portfolio_spec["weighting_strategy"]
-    precomputed = {}
-    if strategy in _CONJUGATE or strategy in ("jeffreys", "jorion", "greyserman"):
-        rebalance_dates = rebalancing_schedule(trading_dates, portfolio_spec["rebalancing_frequency"])
-        frames = calculate_portfolio_weights_batch(rebalance_dates, portfolio_spec, market_data)
-        precomputed = dict(zip(rebalance_dates, frames))
-    portfolio = Portfolio(trading_dates[0], portfolio_spec, precomputed_weights=precomputed)
-    for ts in trading_dates:
-        portfolio.update_portfolio(ts, market_data)
-    return {"portfolio_simple_returns_series": portfolio.get_portfolio_simple_returns(),
-            "portfolio_turnover_series": portfolio.get_portfolio_turnover(),
-            "portfolio_weights_metrics_df": portfolio.get_portfolio_weights_metrics()}
+    rebalance_dates = rebalancing_schedule(trading_dates, portfolio_spec["rebalancing_frequency"])
+    weights, labels, cols, caps = _weights_for_dates(rebalance_dates, portfolio_spec, market_data)
+    tickers = batch.panels_for(market_data, portfolio_spec["rolling_window_frequency"]).tickers
+    return _replay_backtest(trading_dates, rebalance_dates, weights, cols, caps, tickers, portfolio_spec, market_data)

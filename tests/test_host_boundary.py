@@ -106,3 +106,24 @@ def test_excess_log_returns_quirks(pc):
     gap = pd.Series(days).diff().dt.days.dropna().mean()
     expect = np.log(107 / 106) - ((1 + 0.03) ** (gap / 365) - 1)
     assert out["A"].iloc[-1] == pytest.approx(expect, rel=1e-13)
+
+
+def test_day_at_a_time_portfolio_equals_array_replay(pc):
+    """`Portfolio.update_portfolio` (the reference's day-at-a-time form, ref:1127-1219) and the array replay
+    behind `backtest_portfolio` (F2) give the same three outputs."""
+    md, tickers = synthetic.make_market_data(n_tickers=12, n_days=140, seed=31, rf_nan_every=13)
+    days = md["stock_prices_df"].index
+    for strat, rebal in (("vw", "weekly"), ("ew", "daily")):
+        spec = _spec(strat, 7, 25, "daily", rebal)
+        fast = pc.backtest_portfolio(spec, days[40], days[-1], md)
+        dates = [pd.Timestamp(d) for d in days[40:]]
+        p = pc.Portfolio(dates[0], spec)
+        for ts in dates:
+            p.update_portfolio(ts, md)
+        slow = (p.get_portfolio_simple_returns(), p.get_portfolio_turnover(), p.get_portfolio_weights_metrics())
+        for a, b in zip((fast["portfolio_simple_returns_series"], fast["portfolio_turnover_series"],
+                         fast["portfolio_weights_metrics_df"]), slow):
+            assert a.index.equals(b.index)
+            np.testing.assert_allclose(a.to_numpy(), b.to_numpy(), rtol=1e-12, atol=1e-15, equal_nan=True)
+        assert fast["portfolio_simple_returns_series"].name == slow[0].name == strat
+        assert list(fast["portfolio_weights_metrics_df"].columns) == list(slow[2].columns)
