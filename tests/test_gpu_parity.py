@@ -325,3 +325,27 @@ def test_price_front_end_matches_return_panels(native, k, N):
     with pytest.raises(Exception, match="outside the panel"):      # windows are checked against the RETURN rows
         native.posterior_batch("conjugate", k, N, 5.0, panel=P, hf_panel=H, ret_pairs=(pairs(len(P))[0][:-3], pairs(len(P))[1][:-3]),
                                hf_ret_pairs=pairs(len(H)), **common)
+
+
+@pytest.mark.parametrize("k,N", [(5, 20), (33, 80), (100, 250), (150, 200)])
+@pytest.mark.parametrize("strat", ["conjugate", "jeffreys"])
+def test_contiguous_layout_with_ragged_rows_and_risk_free_adjustment(native, k, N, strat):
+    """The lean kernel (contiguous rows, ungathered columns) with everything that is optional in that layout:
+    per-window row counts below n_r / m (ragged last chunk), and the per-row risk-free subtraction of ref:57."""
+    W = 9
+    inp = synthetic.make_kernel_inputs(k, N, W, seed=550000 + k)
+    rng = np.random.default_rng(k)
+    n_r, m = inp["n_r"], inp["m"]
+    lo = max(k + 3, n_r - 20)            # Jeffreys needs more rows than assets (rank of T - t t'/N)
+    n_rows = rng.integers(lo, n_r + 1, W).astype(np.int32); n_rows[0] = n_r; n_rows[1] = max(lo, n_r - 17)
+    rf_adj = rng.normal(1e-4, 2e-5, size=(W, n_r))
+    kw = dict(panel=inp["panel"], start=inp["start"], n_r=n_r, n_rows=n_rows, rf_adj=rf_adj)
+    if strat == "conjugate":
+        hf_count = rng.integers(max(2, m - 30), m + 1, W).astype(np.int32); hf_count[0] = m
+        kw.update(hf_panel=inp["hf_panel"], hf_start=inp["hf_start"], m=m, hf_count=hf_count, w0=inp["w0"], n0=inp["n0"])
+    ref, rstat, raux = oracle.posterior_batch(strat, k, N, 5.0, **kw)
+    got, status, aux = native.posterior_batch(strat, k, N, 5.0, **kw)
+    assert (status == rstat).all()
+    np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(ref).max()))
+    if strat == "conjugate":
+        np.testing.assert_allclose(aux[:, :6], raux[:, :6], rtol=1e-9, atol=1e-12)
