@@ -199,8 +199,11 @@ int tp_batch_gather(tp_batch_t b, int root, double* weights_all, int32_t* status
 /* The same gather without waiting for it, on a second, high-priority stream: from its first use the batch
  * keeps TWO result buffers and tp_batch_run alternates between them, so the gather of step i reads one while
  * the kernel of step i+1 writes the other (a rebalancing schedule that streams batches); no copy is made.
- * Returns at once; tp_synchronize (or tp_batch_download_gathered) waits for it.  Gathers complete in the
- * order they were issued; tp_batch_download always reads the results of the last run. */
+ * The call only REQUESTS the gather: it is put on its stream inside the next tp_batch_run, once that run's
+ * kernel is queued and the host has seen the previous kernel finish (or in tp_synchronize /
+ * tp_batch_download_gathered), so that no stream waits for another stream's event on the device.  Returns
+ * at once; tp_synchronize (or tp_batch_download_gathered) waits for the gather.  Gathers complete in the
+ * order they were requested; tp_batch_download always reads the results of the last run. */
 int tp_batch_gather_async(tp_batch_t b, int root);
 int tp_batch_download_gathered(tp_batch_t b, double* weights_all, int32_t* status_all); /* root only */
 

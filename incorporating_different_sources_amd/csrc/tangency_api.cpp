@@ -37,8 +37,9 @@ struct tp_handle_s {
     bool kernel_timed = false;   // ev0/ev1 bracket the last tp_batch_run and have not been read yet
     // overlapped gather (tp_batch_gather_async): its own high-priority stream next to the kernel stream
     hipStream_t comm_stream = nullptr;
-    hipEvent_t snap = nullptr, cg0 = nullptr, cg1 = nullptr;
-    bool gather_timed = false;      // cg0/cg1 bracket the last asynchronous gather and have not been read yet
+    hipEvent_t cg0 = nullptr, cg1 = nullptr;
+    bool gather_timed = false;
+    tp_batch_t deferred = nullptr;  // batch whose tp_batch_gather_async is requested but not yet on the gather stream      // cg0/cg1 bracket the last asynchronous gather and have not been read yet
 };
 
 struct DevBuf {
@@ -63,6 +64,9 @@ struct tp_batch_s {
     int parity = 0;                                  // pair written by the last run
     hipEvent_t gather_done[2] = {nullptr, nullptr};
     bool gather_pending[2] = {false, false};
+    hipEvent_t snap = nullptr;                       // end of the run whose results the requested gather reads
+    bool gather_req = false;                         // requested by tp_batch_gather_async, issued by flush_gather
+    int gather_req_parity = 0, gather_root = 0;
     double* out_weights() const { return (double*)(parity ? weights2.p : weights.p); }
     int32_t* out_status() const { return (int32_t*)(parity ? status2.p : status.p); }
 };
@@ -309,6 +313,7 @@ int launch(tp_batch_t b, const tp_kargs_t& a, int64_t count, bool timed) {
 }  // namespace
 
 static int harvest_kernel_time(tp_handle_t h);
+static int flush_gather(tp_handle_t h);
 
 extern "C" {
 
@@ -362,7 +367,7 @@ int tp_destroy(tp_handle_t h) {
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (hipEvent_t e : {h->snap, h->cg0, h->cg1})
+    for (hipEvent_t e : {h->cg0, h->cg1})
         if (e) (void)hipEventDestroy(e);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -435,8 +440,10 @@ int tp_batch_destroy(tp_batch_t b) {
     (void)hipSetDevice(b->h->device);
     (void)hipStreamSynchronize(b->h->stream);
     if (b->h->comm_stream) (void)hipStreamSynchronize(b->h->comm_stream);   // a gather may still read the results
+    if (b->h->deferred == b) b->h->deferred = nullptr;
     for (hipEvent_t e : b->gather_done)
         if (e) (void)hipEventDestroy(e);
+    if (b->snap) (void)hipEventDestroy(b->snap);
     DevBuf* all[] = {&b->panel, &b->start, &b->row_idx, &b->n_rows, &b->col_idx, &b->rf_adj, &b->hf_panel, &b->hf_start,
                      &b->hf_row_idx, &b->hf_count, &b->w0, &b->n0, &b->weights, &b->status, &b->aux, &b->dbg,
                      &b->gather_w, &b->gather_s, &b->weights2, &b->status2, &b->stamps, &b->rhs, &b->out_rhs, &b->shift, &b->t_arena, &b->t_rinv, &b->t_ybar, &b->t_zc,
@@ -557,13 +564,18 @@ int tp_batch_run(tp_batch_t b) {
     HIP_TRY(h, hipSetDevice(h->device));
     if (b->pingpong) {
         b->parity ^= 1;
-        if (b->gather_pending[b->parity]) {          // the gather issued two runs ago read this pair
-            HIP_TRY(h, hipStreamWaitEvent(h->stream, b->gather_done[b->parity], 0));
+        if (b->gather_pending[b->parity]) {
+            // The gather issued one run ago read this pair.  The HOST waits for it (the kernel of the previous run
+            // is still executing, so the GPU does not idle): no stream of this library ever waits for another
+            // stream's event on the device - such cross-queue waits cost ~0.1 ms per step (measured).
+            HIP_TRY(h, hipEventSynchronize(b->gather_done[b->parity]));
             b->gather_pending[b->parity] = false;
         }
     }
     tp_kargs_t a = make_kargs(b);
-    return launch(b, a, b->W, true);
+    int rc = launch(b, a, b->W, true);
+    if (rc != TP_OK) return rc;
+    return flush_gather(h);      // with the next kernel queued, put the requested gather of the previous run on its stream
 }
 
 static int harvest_kernel_time(tp_handle_t h) {
@@ -591,6 +603,8 @@ static int harvest_gather_time(tp_handle_t h) {
 int tp_synchronize(tp_handle_t h) {
     if (!h) return TP_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
+    int rcf = flush_gather(h);
+    if (rcf != TP_OK) return rcf;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->comm_stream) {
         HIP_TRY(h, hipStreamSynchronize(h->comm_stream));
@@ -742,6 +756,7 @@ int tp_comm_init(tp_handle_t h, const void* id, int rank, int world) {
 
 int tp_comm_destroy(tp_handle_t h) {
     if (!h) return TP_ERR_INVALID;
+    if (h->deferred) { int rcf = flush_gather(h); if (rcf != TP_OK) return rcf; }
     if (h->comm_stream) { HIP_TRY(h, hipSetDevice(h->device)); HIP_TRY(h, hipStreamSynchronize(h->comm_stream)); }
     if (h->comm) { NCCL_TRY(h, ncclCommDestroy(h->comm)); h->comm = nullptr; }
     h->world = 1; h->rank = 0;
@@ -784,6 +799,38 @@ int tp_batch_gather(tp_batch_t b, int root, double* weights_all, int32_t* status
     return TP_OK;
 }
 
+// Put the requested gather (tp_batch_gather_async) on the gather stream.  Called with the NEXT kernel already
+// queued (tp_batch_run) or when the caller waits anyway: the host waits for the end of the run whose results
+// are gathered, so the gather stream needs no device-side wait for the kernel stream.
+static int flush_gather(tp_handle_t h) {
+    tp_batch_t b = h->deferred;
+    if (!b || !b->gather_req) { h->deferred = nullptr; return TP_OK; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int root = b->gather_root, par = b->gather_req_parity;
+    const size_t nw = (size_t)b->W * b->p.k, ns = (size_t)b->W;
+    const bool is_root = h->rank == root;
+    HIP_TRY(h, hipEventSynchronize(b->snap));
+    // timing events: re-record them only when the previous pair has been read or is already complete
+    bool time_this = true;
+    if (h->gather_timed) {
+        if (hipEventQuery(h->cg1) == hipSuccess) { int rc = harvest_gather_time(h); if (rc != TP_OK) return rc; }
+        else time_this = false;
+    }
+    const double* sw = (const double*)(par ? b->weights2.p : b->weights.p);
+    const int32_t* ss = (const int32_t*)(par ? b->status2.p : b->status.p);
+    if (time_this) HIP_TRY(h, hipEventRecord(h->cg0, h->comm_stream));
+    NCCL_TRY(h, ncclGroupStart());
+    NCCL_TRY(h, ncclGather(sw, is_root ? b->gather_w.p : nullptr, nw, ncclDouble, root, h->comm, h->comm_stream));
+    NCCL_TRY(h, ncclGather(ss, is_root ? b->gather_s.p : nullptr, ns, ncclInt32, root, h->comm, h->comm_stream));
+    NCCL_TRY(h, ncclGroupEnd());
+    if (time_this) { HIP_TRY(h, hipEventRecord(h->cg1, h->comm_stream)); h->gather_timed = true; }
+    HIP_TRY(h, hipEventRecord(b->gather_done[par], h->comm_stream));
+    b->gather_pending[par] = true;
+    b->gather_req = false;
+    h->deferred = nullptr;
+    return TP_OK;
+}
+
 int tp_batch_gather_async(tp_batch_t b, int root) {
     if (!b) return TP_ERR_INVALID;
     tp_handle_t h = b->h;
@@ -794,42 +841,31 @@ int tp_batch_gather_async(tp_batch_t b, int root) {
         int lo = 0, hi = 0;                            // numerically lower = higher priority
         HIP_TRY(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIP_TRY(h, hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, hi));
-        HIP_TRY(h, hipEventCreateWithFlags(&h->snap, hipEventDisableTiming));
         HIP_TRY(h, hipEventCreate(&h->cg0));
         HIP_TRY(h, hipEventCreate(&h->cg1));
     }
     const size_t nw = (size_t)b->W * b->p.k, ns = (size_t)b->W;
     const bool is_root = h->rank == root;
     int rc = TP_OK;
+    if (h->deferred) { rc = flush_gather(h); if (rc != TP_OK) return rc; }     // an earlier request nobody ran after
     if (!b->pingpong) {                                // first use: the second result pair and its events
         rc = ensure(h, b->weights2, sizeof(double) * nw);
         if (rc == TP_OK) rc = ensure(h, b->status2, sizeof(int32_t) * ns);
         if (rc != TP_OK) return rc;
         for (hipEvent_t& e : b->gather_done) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&b->snap, hipEventDisableTiming));
         b->pingpong = true;
     }
     if (is_root) rc = ensure(h, b->gather_w, sizeof(double) * nw * h->world);
     if (rc == TP_OK && is_root) rc = ensure(h, b->gather_s, sizeof(int32_t) * ns * h->world);
     if (rc != TP_OK) return rc;
-    // timing events: re-record them only when the previous pair has been read or is already complete - the
-    // host must never wait here, or the gather of step i-1 would serialise with the launch of step i+1
-    bool time_this = true;
-    if (h->gather_timed) {
-        if (hipEventQuery(h->cg1) == hipSuccess) { rc = harvest_gather_time(h); if (rc != TP_OK) return rc; }
-        else time_this = false;
-    }
-    // gather stream: wait for the run that produced this pair, then one gather of the weights and one of the
-    // statuses to root.  No copy: the next run writes the OTHER pair.
-    HIP_TRY(h, hipEventRecord(h->snap, h->stream));
-    HIP_TRY(h, hipStreamWaitEvent(h->comm_stream, h->snap, 0));
-    if (time_this) HIP_TRY(h, hipEventRecord(h->cg0, h->comm_stream));
-    NCCL_TRY(h, ncclGroupStart());
-    NCCL_TRY(h, ncclGather(b->out_weights(), is_root ? b->gather_w.p : nullptr, nw, ncclDouble, root, h->comm, h->comm_stream));
-    NCCL_TRY(h, ncclGather(b->out_status(), is_root ? b->gather_s.p : nullptr, ns, ncclInt32, root, h->comm, h->comm_stream));
-    NCCL_TRY(h, ncclGroupEnd());
-    if (time_this) { HIP_TRY(h, hipEventRecord(h->cg1, h->comm_stream)); h->gather_timed = true; }
-    HIP_TRY(h, hipEventRecord(b->gather_done[b->parity], h->comm_stream));
-    b->gather_pending[b->parity] = true;
+    // Only a request: the gather goes onto its stream inside the NEXT tp_batch_run, after that run's kernel
+    // is queued (or in tp_synchronize / tp_batch_download_gathered) - see flush_gather.
+    HIP_TRY(h, hipEventRecord(b->snap, h->stream));
+    b->gather_req = true;
+    b->gather_req_parity = b->parity;
+    b->gather_root = root;
+    h->deferred = b;
     b->gathered = true;
     return TP_OK;
 }
@@ -839,6 +875,7 @@ int tp_batch_download_gathered(tp_batch_t b, double* weights_all, int32_t* statu
     tp_handle_t h = b->h;
     if (!b->gathered || !b->gather_w.p) return fail(h, TP_ERR_INVALID, "nothing gathered on this rank (root only, after tp_batch_gather)");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->deferred) { int rcf = flush_gather(h); if (rcf != TP_OK) return rcf; }
     if (h->comm_stream) {                              // an asynchronous gather may still be filling gather_w
         HIP_TRY(h, hipStreamSynchronize(h->comm_stream));
     }
