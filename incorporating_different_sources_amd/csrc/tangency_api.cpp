@@ -114,6 +114,14 @@ void release(DevBuf& b) {
     b.bytes = 0;
 }
 
+// a device buffer that lives for one call: freed on every return path
+struct ScratchBuf : DevBuf {
+    ScratchBuf() = default;
+    ScratchBuf(const ScratchBuf&) = delete;
+    ScratchBuf& operator=(const ScratchBuf&) = delete;
+    ~ScratchBuf() { release(*this); }
+};
+
 int check_params(tp_handle_t h, const tp_params_t* p, int64_t W) {
     if (!p) return fail(h, TP_ERR_INVALID, "params is NULL");
     if (W < 0) return fail(h, TP_ERR_INVALID, "W=%lld < 0", (long long)W);
@@ -396,7 +404,7 @@ int tp_log_returns(tp_handle_t h, const double* prices, int64_t price_rows, int3
     int rc = validate_pairs(h, "ret", num, den, n_out, price_rows);
     if (rc != TP_OK) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
-    DevBuf dp, dn, dd, dout;
+    ScratchBuf dp, dn, dd, dout;
     rc = put(h, dp, prices, sizeof(double) * (size_t)price_rows * ld);
     if (rc == TP_OK) rc = put(h, dn, num, sizeof(int32_t) * (size_t)n_out);
     if (rc == TP_OK) rc = put(h, dd, den, sizeof(int32_t) * (size_t)n_out);
@@ -414,7 +422,6 @@ int tp_log_returns(tp_handle_t h, const double* prices, int64_t price_rows, int3
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         rc = harvest_kernel_time(h);
     }
-    release(dp); release(dn); release(dd); release(dout);
     return rc;
 }
 
@@ -466,7 +473,7 @@ int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in) {
     h->kernel_timed = false;
 #define PUT(buf, ptr, bytes) do { rc = put(h, b->buf, (ptr), (bytes)); if (rc != TP_OK) return rc; } while (0)
     // panels: log-returns as given, or formed on the device from prices (returns_frontend.hip)
-    DevBuf prices, pnum, pden;
+    ScratchBuf prices, pnum, pden;       // price staging of the front-end
     auto panel_in = [&](DevBuf& dst, const double* src, int64_t rows, int ld, const int32_t* num, const int32_t* den,
                         int64_t n_out) -> int {
         if (!num) return put(h, dst, src, sizeof(double) * (size_t)rows * ld);
@@ -482,7 +489,7 @@ int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in) {
         return TP_OK;
     };
     rc = panel_in(b->panel, in->panel, in->panel_rows, in->panel_ld, in->ret_num, in->ret_den, in->ret_rows);
-    if (rc != TP_OK) { release(prices); release(pnum); release(pden); return rc; }
+    if (rc != TP_OK) return rc;
     PUT(start, in->start, sizeof(int64_t) * (size_t)W);
     PUT(row_idx, in->row_idx, sizeof(int32_t) * (size_t)W * p.n_r);
     PUT(n_rows, in->n_rows, sizeof(int32_t) * (size_t)W);
@@ -490,7 +497,7 @@ int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in) {
     PUT(rf_adj, in->rf_adj, sizeof(double) * (size_t)W * p.n_r);
     if (conj) {
         rc = panel_in(b->hf_panel, in->hf_panel, in->hf_rows, in->hf_ld, in->hf_ret_num, in->hf_ret_den, in->hf_ret_rows);
-        if (rc != TP_OK) { release(prices); release(pnum); release(pden); return rc; }
+        if (rc != TP_OK) return rc;
         PUT(hf_start, in->hf_start, sizeof(int64_t) * (size_t)W);
         PUT(hf_row_idx, in->hf_row_idx, sizeof(int32_t) * (size_t)W * p.m);
         PUT(hf_count, in->hf_count, sizeof(int32_t) * (size_t)W);
@@ -498,7 +505,6 @@ int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in) {
         PUT(n0, in->n0, sizeof(double) * (size_t)W);
     }
 #undef PUT
-    release(prices); release(pnum); release(pden);
     b->panel_ld = in->panel_ld;
     b->hf_ld = conj ? in->hf_ld : 0;
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
