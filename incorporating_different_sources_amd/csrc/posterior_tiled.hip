@@ -62,6 +62,21 @@ __device__ __forceinline__ void pair_decode(int p, int n, int& a, int& b) {
     a = i; b = i + rem;
 }
 
+// XCD-aware mapping of a 1-D grid to (window, tile) for the kernels that run SEVERAL workgroups per window.
+// MI355X deals consecutive workgroup ids round-robin to its 8 XCDs, each with its own 4 MB L2.  With
+// (window, tile) = (blockIdx.x, blockIdx.y) the tiles of one window ran on one XCD but thousands of workgroups
+// apart, so every tile re-read the window's rows (or arena tiles) from HBM / Infinity Cache: the Gram kernel
+// moved 48 GB per launch at k = 500.  Here id -> xcd = id % 8, slot = id / 8, window = 8 (slot / NT) + xcd,
+// tile = slot % NT: the NT tiles of a window are consecutive ON ONE XCD, whose L2 then serves the re-reads.
+__device__ __forceinline__ bool xcd_window_tile(int NT, long long G, long long& wl, int& tile) {
+    const long long id = blockIdx.x;
+    const long long slot = id >> 3;
+    wl = 8 * (slot / NT) + (id & 7);
+    tile = (int)(slot % NT);
+    return wl < G;
+}
+inline dim3 xcd_grid(int NT, long long G) { return dim3((unsigned)(((G + 7) / 8) * 8 * NT)); }
+
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(NTHREADS) tiled_prior_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws) {
     __shared__ double red[NTHREADS];
@@ -127,15 +142,20 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const long long wl = blockIdx.x;
-    const long long w = A.w_first + wl;
     const int k = A.k, KP = ws.KP, NS = ws.NS;
+    const int T = NS - 1 - j;                                  // TRSM / SYRK: block rows and columns behind step j
+    long long wl;
+    int tile;
+    if (!xcd_window_tile(MODE == MODE_GRAM ? NS * (NS + 1) / 2 : (MODE == MODE_TRSM ? T : T * (T + 1) / 2),
+                         A.w_count, wl, tile))
+        return;
+    const long long w = A.w_first + wl;
     double* M = ws.arena + wl * (long long)KP * KP;
 
     int SI, SJ;
-    if (MODE == MODE_GRAM) pair_decode(blockIdx.y, NS, SI, SJ);
-    else if (MODE == MODE_TRSM) { SI = j; SJ = j + 1 + blockIdx.y; }
-    else { int a, b; pair_decode(blockIdx.y, NS - 1 - j, a, b); SI = j + 1 + a; SJ = j + 1 + b; }
+    if (MODE == MODE_GRAM) pair_decode(tile, NS, SI, SJ);
+    else if (MODE == MODE_TRSM) { SI = j; SJ = j + 1 + tile; }
+    else { int a, b; pair_decode(tile, T, a, b); SI = j + 1 + a; SJ = j + 1 + b; }
 
     // row sources
     const int* cols = A.col_idx ? A.col_idx + w * k : nullptr;
@@ -302,14 +322,150 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
             M[(long long)(64 * SI + 16 * wv + fq + 4 * r) * KP + 64 * SJ + 16 * b + fr] = acc[b][r];
 }
 
+// ------------------------------------------------------------------------------------------------
+// The Gram super-tile again, for panels whose byte offsets fit 32 bits (every realistic one), written for the
+// vector-instruction budget (see posterior_fused_impl.h, staging): the column selects of the padded / border
+// columns exist only in EDGE super-tiles (the instantiation is picked per workgroup, uniformly), the intraday
+// and the daily chunks are two straight-line code paths, addresses are one 32-bit row offset plus eight
+// loop-invariant column offsets on a uniform base.  Same loads, same arithmetic, same order as
+// tile64_kernel<MODE_GRAM>, which stays as the path for panels of 4 GiB and more.
+template <bool EDGE>
+__device__ __forceinline__ void gram64_lean_body(const tp_kargs_t& A, const tp_tiled_ws_t& ws, double* lds,
+                                                 const long long wl, const int SI, const int SJ) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const long long w = A.w_first + wl;
+    const int k = A.k, KP = ws.KP;
+    double* M = ws.arena + wl * (long long)KP * KP;
+    const int* cols = A.col_idx ? A.col_idx + w * k : nullptr;
+    const bool conj = A.strategy == 0;
+    const int mm = conj ? (A.hf_count ? A.hf_count[w] : A.m) : 0;
+    const int nr = A.n_rows ? A.n_rows[w] : A.n_r;
+    const int* hridx = (conj && A.hf_row_idx) ? A.hf_row_idx + w * (long long)A.m : nullptr;
+    const int* dridx = A.row_idx ? A.row_idx + w * (long long)A.n_r : nullptr;
+    const double* rf = A.rf_adj ? A.rf_adj + w * (long long)A.n_r : nullptr;
+    const double sqs = conj ? ws.scal[wl * 8 + 1] : 0.0;
+    const double* ybar = ws.ybar + wl * KP;
+    const double* zc = ws.zc + wl * (long long)A.m;
+    // uniform bases: the window's first row (contiguous rows) or the panel (explicit rows)
+    const char* hub = conj ? (const char*)(hridx ? A.hf_panel : A.hf_panel + (A.hf_start ? A.hf_start[w] : 0) * (long long)A.hf_ld) : nullptr;
+    const char* dub = (const char*)(dridx ? A.panel : A.panel + (A.start ? A.start[w] : 0) * (long long)A.panel_ld);
+    const unsigned hld8 = (unsigned)A.hf_ld * 8u, dld8 = (unsigned)A.panel_ld * 8u;
+
+    const int srow = tid >> 4, cb = tid & 15;
+    unsigned co[8];          // byte offset of this lane's eight columns (A half: i < 4, B half: i >= 4)
+    double yb[8];            // intraday column means of those columns
+    bool cval[8], cbord[8];  // EDGE only: real asset column / border column
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int gc = 64 * ((i >> 2) ? SJ : SI) + cb + 16 * (i & 3);
+        cval[i] = !EDGE || gc < k;
+        cbord[i] = EDGE && gc == k;
+        const int gcl = cval[i] ? gc : k - 1;                      // padding columns re-read column k-1 (masked below)
+        co[i] = 8u * (unsigned)(cols ? cols[gcl] : gcl);
+        yb[i] = (conj && cval[i]) ? ybar[gcl] : 0.0;
+    }
+    d4 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
+
+    const int hchunks = (mm + CH - 1) / CH;
+    const int nchunks = hchunks + (nr + CH - 1) / CH;
+    double v[8];
+    double rowc = 0.0;      // per-row constant: border entry (intraday) / risk-free adjustment (daily)
+    auto load = [&](int ch) __attribute__((always_inline)) {
+        if (ch < hchunks) {
+            const int r = ch * CH + srow;
+            const int rc = r < mm ? r : mm - 1;
+            const unsigned ro = __umul24(hridx ? (unsigned)hridx[rc] : (unsigned)rc, hld8);
+            rowc = zc[rc];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *(const double*)(hub + (size_t)(ro + co[i]));
+        } else {
+            const int r = (ch - hchunks) * CH + srow;
+            const int rc = r < nr ? r : nr - 1;
+            const unsigned ro = __umul24(dridx ? (unsigned)dridx[rc] : (unsigned)rc, dld8);
+            rowc = rf ? rf[rc] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *(const double*)(dub + (size_t)(ro + co[i]));
+        }
+    };
+    auto store = [&](double* buf, int ch) __attribute__((always_inline)) {
+        if (ch < hchunks) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] = sqs * (v[i] - yb[i]);                                       // sqrt(s) (y - ybar)
+                if (EDGE) v[i] = cval[i] ? v[i] : (cbord[i] ? rowc : 0.0);         // border: c sqrt(s) z_r
+            }
+            if ((ch + 1) * CH > mm) {                                              // ragged chunk (uniform)
+                const bool rowv = ch * CH + srow < mm;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = rowv ? v[i] : 0.0;
+            }
+        } else {
+            if (rf) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] -= rowc;                          // x - rf (ref:57)
+            }
+            if (EDGE) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = cval[i] ? v[i] : (cbord[i] ? 1.0 : 0.0);   // border: ones -> t
+            }
+            if ((ch - hchunks + 1) * CH > nr) {
+                const bool rowv = (ch - hchunks) * CH + srow < nr;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = rowv ? v[i] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) buf[srow * LDX + 64 * (i >> 2) + cb + 16 * (i & 3)] = v[i];
+    };
+    if (nchunks > 0) { load(0); store(lds, 0); }
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        double* cur = lds + (ch & 1) * CH * LDX;
+        double* nxt = lds + ((ch + 1) & 1) * CH * LDX;
+        const bool more = ch + 1 < nchunks;
+        if (more) load(ch + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const double* lb = cur + fq * LDX + fr;
+#pragma unroll
+        for (int s4 = 0; s4 < CH / 4; ++s4) {
+            const double a = lb[4 * s4 * LDX + 16 * wv];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, lb[4 * s4 * LDX + 64 + 16 * b], acc[b], 0, 0, 0);
+        }
+        if (more) store(nxt, ch + 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            M[(long long)(64 * SI + 16 * wv + fq + 4 * r) * KP + 64 * SJ + 16 * b + fr] = acc[b][r];
+}
+
+__global__ void __launch_bounds__(NTHREADS) tiled_gram_lean_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * CH * LDX];
+    long long wl;
+    int tile, SI, SJ;
+    if (!xcd_window_tile(ws.NS * (ws.NS + 1) / 2, A.w_count, wl, tile)) return;
+    pair_decode(tile, ws.NS, SI, SJ);
+    if (64 * SJ + 63 < A.k) gram64_lean_body<false>(A, ws, lds, wl, SI, SJ);     // SI <= SJ: every column is a real asset
+    else gram64_lean_body<true>(A, ws, lds, wl, SI, SJ);
+}
+
 // Jeffreys: J = T - t t'/N on one super-tile (t = border column k); rows/cols >= k untouched.
 __global__ void __launch_bounds__(NTHREADS) tiled_rank1_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws) {
     const int tid = threadIdx.x;
-    const long long wl = blockIdx.x;
     const int k = A.k, KP = ws.KP, NS = ws.NS;
+    long long wl;
+    int tile, SI, SJ;
+    if (!xcd_window_tile(NS * (NS + 1) / 2, A.w_count, wl, tile)) return;
     double* M = ws.arena + wl * (long long)KP * KP;
-    int SI, SJ;
-    pair_decode(blockIdx.y, NS, SI, SJ);
+    pair_decode(tile, NS, SI, SJ);
     const long long w = A.w_first + wl;
     const double invN = A.center_rows == 2 ? 0.0
                       : 1.0 / (double)(A.center_rows ? (A.n_rows ? A.n_rows[w] : A.n_r) : A.N);
@@ -523,15 +679,18 @@ hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStre
     const int NS = ws.NS, NSB = ws.NSB;
     const bool conj = a.strategy == 0;
     if (conj) hipLaunchKernelGGL(tiled_prior_kernel, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
-    hipLaunchKernelGGL(tile64_kernel<MODE_GRAM>, dim3(G, NS * (NS + 1) / 2), dim3(NTHREADS), 0, stream, a, ws, 0);
-    if (!conj) hipLaunchKernelGGL(tiled_rank1_kernel, dim3(G, NS * (NS + 1) / 2), dim3(NTHREADS), 0, stream, a, ws);
+    // 32-bit offsets for both panels in the layout they come in (explicit rows: bit 0, contiguous: bit 1)?
+    const bool lean = (a.panel_off32 & (a.row_idx ? 1 : 2)) && (!conj || (a.hf_off32 & (a.hf_row_idx ? 1 : 2)));
+    if (lean) hipLaunchKernelGGL(tiled_gram_lean_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws);
+    else hipLaunchKernelGGL(tile64_kernel<MODE_GRAM>, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws, 0);
+    if (!conj) hipLaunchKernelGGL(tiled_rank1_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws);
     hipLaunchKernelGGL(tiled_clear_kernel, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
     for (int j = 0; j < NSB; ++j) {
         hipLaunchKernelGGL(tiled_diag_kernel, dim3(G), dim3(NTHREADS), 0, stream, a, ws, j);
         const int T = NS - 1 - j;
         if (T > 0) {
-            hipLaunchKernelGGL(tile64_kernel<MODE_TRSM>, dim3(G, T), dim3(NTHREADS), 0, stream, a, ws, j);
-            hipLaunchKernelGGL(tile64_kernel<MODE_SYRK>, dim3(G, T * (T + 1) / 2), dim3(NTHREADS), 0, stream, a, ws, j);
+            hipLaunchKernelGGL(tile64_kernel<MODE_TRSM>, xcd_grid(T, G), dim3(NTHREADS), 0, stream, a, ws, j);
+            hipLaunchKernelGGL(tile64_kernel<MODE_SYRK>, xcd_grid(T * (T + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws, j);
         }
     }
     const size_t smem = sizeof(double) * (size_t)(ws.KP + SB);
