@@ -495,11 +495,8 @@ __device__ __forceinline__ void static_for_t(F&& f) {
 
 __global__ void __launch_bounds__(NTHREADS) tiled_diag_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws, const int j) {
     constexpr int LD = SB + 1;
-    constexpr int LT = SB / 2 + 1;
-    __shared__ double Ab[SB * LD];             // R (for the inverse), written once after the factorisation
-    __shared__ double Rv[SB * LD];             // R^-1
-    __shared__ double Tm[(SB / 2) * LT];       // product scratch of the blocked inverse (76 KB in all: 2 blocks per CU)
-    __shared__ double rowp[2][SB];             // the pivot row, published by its owners (double-buffered)
+    __shared__ double Tt[SB * LD];             // transpose buffer for R^-1 on the way out
+    __shared__ double rowp[2][2 * SB];         // the pivot row (block | identity part), published by its owners
     __shared__ int bad;
     const int tid = threadIdx.x;
     const long long wl = blockIdx.x;
@@ -507,21 +504,23 @@ __global__ void __launch_bounds__(NTHREADS) tiled_diag_kernel(const tp_kargs_t A
     double* M = ws.arena + wl * (long long)KP * KP;
     const int npiv = (k - 64 * j < SB) ? (k - 64 * j) : SB;
     if (tid == 0) bad = 0;
-    // Right-looking Cholesky with the block in REGISTERS: thread (g, c) holds column c of rows g, g+4, ... (16
-    // values).  Per pivot the owners publish the (unscaled) pivot row through LDS, ONE barrier, then every thread
-    // updates its own registers from LDS broadcasts of the multipliers - no read-modify-write of an LDS image,
-    // whose dependent latencies made a pivot cost ~3.7 k cycles.  Fully unrolled so that register indices are static.
+    // Right-looking Cholesky of the 64 x 64 block with the block AND 64 identity columns in REGISTERS: thread
+    // (g, c) holds column c of rows g, g+4, ... of both (2 x 16 values).  Per pivot the owners publish the
+    // (unscaled) pivot row through LDS, ONE barrier, then every thread updates its own registers from LDS
+    // broadcasts of the multipliers.  The identity columns come out as R^-T (as in the register-tile kernel's
+    // phase F), i.e. R_jj^-1 needs no pass of its own; rows >= npiv (border row, padding) are never touched and
+    // stay identity rows.  Fully unrolled so that register indices are static.
     const int c = tid & 63, g = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double a[16];
+    double a[16], m[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         a[r] = M[(long long)(64 * j + 4 * r + g) * KP + 64 * j + c];
-        Rv[(4 * r + g) * LD + c] = 0.0;
+        m[r] = (4 * r + g == c) ? 1.0 : 0.0;
     }
     static_for_t<0, 64>([&](auto pc) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value, r = p >> 2, g4 = p & 3;
         if (p < npiv) {                                                  // uniform
-            if (g == g4) rowp[p & 1][c] = a[r];
+            if (g == g4) { rowp[p & 1][c] = a[r]; rowp[p & 1][SB + c] = m[r]; }
             __syncthreads();
             const double d = rowp[p & 1][p];
             if (!(d > 0.0) && tid == 0) bad = 1;
@@ -531,71 +530,31 @@ __global__ void __launch_bounds__(NTHREADS) tiled_diag_kernel(const tp_kargs_t A
             e = fma(-(d * rinv), rinv, 1.0);
             rinv = fma(0.5 * rinv, e, rinv);
             const double sc = rowp[p & 1][c] * rinv;                     // R[p][c]
-            if (g == g4) a[r] = (c >= p) ? sc : 0.0;                     // row p is final (all 64 columns: the border rides along)
+            const double si = rowp[p & 1][SB + c] * rinv;                // (R^-T)[p][c]
+            if (g == g4) { a[r] = (c >= p) ? sc : 0.0; m[r] = si; }      // row p is final (all 64 columns: the border rides along)
 #pragma unroll
             for (int rr = r; rr < 16; ++rr) {
                 const int i = 4 * rr + g;                                // wave-uniform row
                 if (i > p && i < npiv) {
-                    const double m = rowp[p & 1][i] * rinv;              // LDS broadcast
-                    if (c >= i) a[rr] = fma(-m, sc, a[rr]);
+                    const double mu = rowp[p & 1][i] * rinv;             // LDS broadcast
+                    if (c >= i) a[rr] = fma(-mu, sc, a[rr]);
+                    m[rr] = fma(-mu, si, m[rr]);
                 }
             }
         }
     });
-    __syncthreads();
+    // factored rows back to the arena (upper part; the border column of the last block is y)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Ab[(4 * r + g) * LD + c] = a[r];
-    __syncthreads();
-    // factored rows back to the arena (upper part; the border column of the last block is y), then the matrix
-    // that is inverted: blockdiag(R[0:npiv, 0:npiv], I) - rows >= npiv (border row, padding) are identity rows
-    // and the columns >= npiv of the real rows do not take part.
-    for (int e = tid; e < SB * SB; e += NTHREADS) {
-        const int i = e >> 6, cc = e & 63;
-        if (i < npiv && cc >= i) M[(long long)(64 * j + i) * KP + 64 * j + cc] = Ab[i * LD + cc];
-        if (i >= npiv) Ab[i * LD + cc] = (i == cc) ? 1.0 : 0.0;
-        else if (cc >= npiv) Ab[i * LD + cc] = 0.0;
+    for (int r = 0; r < 16; ++r) {
+        const int i = 4 * r + g;
+        if (i < npiv && c >= i) M[(long long)(64 * j + i) * KP + 64 * j + c] = a[r];
+        Tt[i * LD + c] = m[r];                                           // (R^-T)[i][c] = (R^-1)[c][i]
     }
     __syncthreads();
-    // R^-1 by blocks: the four 16 x 16 diagonal blocks by back substitution (16 threads each, one column per
-    // thread), then [[A, B], [0, C]]^-1 = [[A^-1, -A^-1 B C^-1], [0, C^-1]] at the 32- and the 64-level with
-    // all 256 threads on the products: the dependent chain is ~450 operations instead of ~2000.
-    if (tid < SB) {
-        const int b0 = 16 * (tid >> 4), cc = tid & 15;
-        for (int i = 15; i >= 0; --i) {
-            double x = 0.0;
-            if (i <= cc) {
-                double sum = (i == cc) ? 1.0 : 0.0;
-                for (int q = i + 1; q <= cc; ++q) sum = fma(-Ab[(b0 + i) * LD + b0 + q], Rv[(b0 + q) * LD + b0 + cc], sum);
-                x = sum / Ab[(b0 + i) * LD + b0 + i];
-            }
-            Rv[(b0 + i) * LD + b0 + cc] = x;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int h = 16; h <= 32; h *= 2) {                 // half-size of the blocks being joined
-        const int npairs = SB / (2 * h);                // 2 pairs of 16-blocks, then 1 pair of 32-blocks
-        // T = B C^-1   (B = R[r0 : r0+h, r0+h : r0+2h], C^-1 = Rv of the lower-right block, upper triangular)
-        for (int e = tid; e < npairs * h * h; e += NTHREADS) {
-            const int pr = e / (h * h), i = (e / h) % h, cc = e % h, r0 = 2 * h * pr;
-            double sum = 0.0;
-            for (int q = 0; q <= cc; ++q) sum = fma(Ab[(r0 + i) * LD + r0 + h + q], Rv[(r0 + h + q) * LD + r0 + h + cc], sum);
-            Tm[(h * pr + i) * LT + cc] = sum;
-        }
-        __syncthreads();
-        // X = -A^-1 T
-        for (int e = tid; e < npairs * h * h; e += NTHREADS) {
-            const int pr = e / (h * h), i = (e / h) % h, cc = e % h, r0 = 2 * h * pr;
-            double sum = 0.0;
-            for (int q = i; q < h; ++q) sum = fma(Rv[(r0 + i) * LD + r0 + q], Tm[(h * pr + q) * LT + cc], sum);
-            Rv[(r0 + i) * LD + r0 + h + cc] = -sum;
-        }
-        __syncthreads();
-    }
     double* rinvp = ws.rinv + (wl * ws.NSB + j) * (long long)(SB * SB);
     for (int e = tid; e < SB * SB; e += NTHREADS) {
         const int i = e >> 6, cc = e & 63;
-        rinvp[e] = Rv[i * LD + cc];
+        rinvp[e] = Tt[cc * LD + i];                                      // row-major R^-1
     }
     if (tid == 0 && bad) ws.flags[wl] = 1;
 }
