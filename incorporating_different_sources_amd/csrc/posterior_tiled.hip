@@ -79,8 +79,15 @@ __device__ __forceinline__ bool xcd_window_tile(int NT, long long G, long long& 
 inline dim3 xcd_grid(int NT, long long G) { return dim3((unsigned)(((G + 7) / 8) * 8 * NT)); }
 
 // ------------------------------------------------------------------------------------------------
+// ONE pass over the intraday window (the kernel is HBM-bound: the window is 1.5 MB at k=500, 13.7 MB at k=1000,
+// used by nothing else): a wavefront per row, lane l holds columns l, l+64, ... - the column sums and w0 stay in
+// registers (NCI = ceil(k/64) of each, a template parameter so that the indices are static), and the same
+// loaded values give u_r = y_r . w0.  Then z_r = u_r - ybar . w0  (= (y_r - ybar) . w0 of ref:317-333 with the
+// subtraction taken out of the sum).
+template <int NCI>
 __global__ void __launch_bounds__(NTHREADS) tiled_prior_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws) {
-    __shared__ double red[NTHREADS];
+    __shared__ double part[4][64 * NCI];
+    __shared__ double red[4];
     __shared__ double sc[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const long long wl = blockIdx.x;                 // window inside the batch
@@ -92,38 +99,59 @@ __global__ void __launch_bounds__(NTHREADS) tiled_prior_kernel(const tp_kargs_t 
     const long long first = A.hf_start ? A.hf_start[w] : 0;
     double* ybar = ws.ybar + wl * ws.KP;
     double* zc = ws.zc + wl * (long long)A.m;
-    // column means: thread per column, rows streamed with 8 loads in flight
-    for (int c = tid; c < ws.KP; c += NTHREADS) {
-        double sum = 0.0;
-        if (c < k) {
-            const int gc = cols ? cols[c] : c;
-#pragma unroll 8
-            for (int r = 0; r < mm; ++r) {
-                const long long row = ridx ? (long long)ridx[r] : first + r;
-                sum += A.hf_panel[row * (long long)A.hf_ld + gc];
-            }
-            sum /= (double)mm;
-        }
-        ybar[c] = sum;
+    int gc[NCI];
+    double w0r[NCI], cs[NCI];
+#pragma unroll
+    for (int i = 0; i < NCI; ++i) {
+        const int c = lane + 64 * i;
+        const int cl = c < k ? c : k - 1;                               // padding lanes re-read column k-1, weight 0
+        gc[i] = cols ? cols[cl] : cl;
+        w0r[i] = c < k ? A.w0[w * k + c] : 0.0;
+        cs[i] = 0.0;
     }
-    __syncthreads();
-    // z_r = (y_r - ybar) . w0 : one wavefront per row
-    double zz = 0.0;
-    for (int r = wv; r < mm; r += 4) {
+    for (int r = wv; r < mm; r += 4) {                                  // rows r = wv (mod 4), in order
         const long long row = ridx ? (long long)ridx[r] : first + r;
         const double* p = A.hf_panel + row * (long long)A.hf_ld;
-        double z = 0.0;
-        for (int c = lane; c < k; c += 64) z = fma(p[cols ? cols[c] : c] - ybar[c], A.w0[w * k + c], z);
-        z = wave_sum64(z);
-        if (lane == 0) zc[r] = z;
-        zz = fma(z, z, zz);          // identical in every lane of the wave
+        double y[NCI];
+#pragma unroll
+        for (int i = 0; i < NCI; ++i) y[i] = p[gc[i]];
+        double u = 0.0;
+#pragma unroll
+        for (int i = 0; i < NCI; ++i) { cs[i] += y[i]; u = fma(y[i], w0r[i], u); }
+        u = wave_sum64(u);
+        if (lane == 0) zc[r] = u;
     }
+#pragma unroll
+    for (int i = 0; i < NCI; ++i) part[wv][lane + 64 * i] = cs[i];
+    __syncthreads();
+    // column means (fixed order over the four row classes) and ybar . w0
+    double yw = 0.0;
+    for (int c = tid; c < ws.KP; c += NTHREADS) {
+        double m = 0.0;
+        if (c < k) {
+            m = (((part[0][c] + part[1][c]) + part[2][c]) + part[3][c]) / (double)mm;
+            yw = fma(m, A.w0[w * k + c], yw);
+        }
+        ybar[c] = m;
+    }
+    yw = wave_sum64(yw);
+    if (lane == 0) red[wv] = yw;
+    __syncthreads();
+    const double ybw = ((red[0] + red[1]) + red[2]) + red[3];
+    __syncthreads();
+    double zz = 0.0;
+    for (int r = tid; r < mm; r += NTHREADS) {
+        const double z = zc[r] - ybw;
+        zc[r] = z;
+        zz = fma(z, z, zz);
+    }
+    zz = wave_sum64(zz);
     if (lane == 0) red[wv] = zz;
     __syncthreads();
     if (tid == 0) {
         const double n0 = A.n0[w];
         const double s = n0 * ((double)mm / ((double)mm - 1.0));
-        const double q0 = s * (red[0] + red[1] + red[2] + red[3]);
+        const double q0 = s * (((red[0] + red[1]) + red[2]) + red[3]);
         const double a = n0 + k + 2;
         const double c = (2 * n0) / (a + sqrt(a * a + 4 * n0 * q0));
         double* o = ws.scal + wl * 8;
@@ -662,7 +690,12 @@ hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStre
     if (G <= 0) return hipSuccess;
     const int NS = ws.NS, NSB = ws.NSB;
     const bool conj = a.strategy == 0;
-    if (conj) hipLaunchKernelGGL(tiled_prior_kernel, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
+    if (conj) {
+        const int nci = (a.k + 63) / 64;
+        if (nci <= 8) hipLaunchKernelGGL(tiled_prior_kernel<8>, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
+        else if (nci <= 16) hipLaunchKernelGGL(tiled_prior_kernel<16>, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
+        else hipLaunchKernelGGL(tiled_prior_kernel<32>, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
+    }
     // 32-bit offsets for both panels in the layout they come in (explicit rows: bit 0, contiguous: bit 1)?
     const bool lean = (a.panel_off32 & (a.row_idx ? 1 : 2)) && (!conj || (a.hf_off32 & (a.hf_row_idx ? 1 : 2)));
     if (lean) hipLaunchKernelGGL(tiled_gram_lean_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws);
