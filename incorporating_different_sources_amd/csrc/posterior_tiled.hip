@@ -14,7 +14,7 @@
 //   tiled_diag_kernel    block step j: Cholesky of the 64 x 64 diagonal block in LDS (upper, R'R) and
 //                        its inverse R_jj^-1 (ref:485's inverse is never formed for the full matrix)
 //   tile64_kernel<TRSM>  R_jJ = R_jj^-T A_jJ as an MFMA product with R_jj^-1 as the k-major A image
-//   tile64_kernel<SYRK>  trailing update A_IJ -= R_jI' R_jJ
+//   tile64_kernel<SYRK>  left-looking update of block row j: A_jJ -= sum_{q<j} R_qj' R_qJ, J >= j
 //   tiled_solve_kernel   y = border column (forward substitution happened on the way), q1 = y'y,
 //                        blocked back substitution, weights (ref:572-575, 836 / 849), status, aux
 //
@@ -172,11 +172,10 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int k = A.k, KP = ws.KP, NS = ws.NS;
-    const int T = NS - 1 - j;                                  // TRSM / SYRK: block rows and columns behind step j
+    const int T = NS - 1 - j;                                  // TRSM: block columns to the right of step j
     long long wl;
     int tile;
-    if (!xcd_window_tile(MODE == MODE_GRAM ? NS * (NS + 1) / 2 : (MODE == MODE_TRSM ? T : T * (T + 1) / 2),
-                         A.w_count, wl, tile))
+    if (!xcd_window_tile(MODE == MODE_GRAM ? NS * (NS + 1) / 2 : (MODE == MODE_TRSM ? T : T + 1), A.w_count, wl, tile))
         return;
     const long long w = A.w_first + wl;
     double* M = ws.arena + wl * (long long)KP * KP;
@@ -184,7 +183,7 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
     int SI, SJ;
     if (MODE == MODE_GRAM) pair_decode(tile, NS, SI, SJ);
     else if (MODE == MODE_TRSM) { SI = j; SJ = j + 1 + tile; }
-    else { int a, b; pair_decode(tile, T, a, b); SI = j + 1 + a; SJ = j + 1 + b; }
+    else { SI = j; SJ = j + tile; }             // SYRK (left-looking): tile (j, J), J >= j, gets ALL earlier block rows
 
     // row sources
     const int* cols = A.col_idx ? A.col_idx + w * k : nullptr;
@@ -250,7 +249,7 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
     const bool interior = MODE == MODE_GRAM && 64 * SJ + 63 < k;     // SI <= SJ: both column groups are real assets
     // GRAM rows: [intraday rows, padded to whole chunks][daily rows]; a chunk is purely one kind
     const int hchunks = (mm + CH - 1) / CH;
-    const int nchunks = (MODE == MODE_GRAM) ? hchunks + (nr + CH - 1) / CH : SB / CH;
+    const int nchunks = (MODE == MODE_GRAM) ? hchunks + (nr + CH - 1) / CH : (MODE == MODE_SYRK ? (SB / CH) * j : SB / CH);
     double v[8];
     double rowc = 0.0;      // per-row constant: border entry (intraday) / risk-free adjustment (daily)
     bool rowv = false;
@@ -287,9 +286,10 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
                 for (int i = 0; i < 8; ++i) v[i] = base[pcol[i]];
             }
         } else {
-            const int r = ch * CH + srow;
-            const double* rowA = (MODE == MODE_TRSM) ? rinv + r * SB : M + (long long)(64 * j + r) * KP;
-            const double* rowB = M + (long long)(64 * j + r) * KP;
+            // TRSM: the 64 rows of block row j; SYRK: the rows of block rows 0 .. j-1, one after the other
+            const int r = (MODE == MODE_SYRK) ? ch * CH + srow : 64 * j + ch * CH + srow;
+            const double* rowA = (MODE == MODE_TRSM) ? rinv + (ch * CH + srow) * SB : M + (long long)r * KP;
+            const double* rowB = M + (long long)r * KP;
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = rowA[pcol[i]];
 #pragma unroll
@@ -335,11 +335,11 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
         const double* lb = cur + fq * LDX + fr;
 #pragma unroll
         for (int s4 = 0; s4 < CH / 4; ++s4) {
-            double a = lb[4 * s4 * LDX + 16 * wv];
-            if (MODE == MODE_SYRK) a = -a;
+            const double a = lb[4 * s4 * LDX + 16 * wv];
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, lb[4 * s4 * LDX + 64 + 16 * b], acc[b], 0, 0, 0);
+            for (int b = 0; b < 4; ++b)      // SYRK: acc -= a'b through the negate bit of the f64 MFMA (BLGP bit 0)
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, lb[4 * s4 * LDX + 64 + 16 * b], acc[b], 0, 0,
+                                                              MODE == MODE_SYRK ? 1 : 0);
         }
         if (more) store(nxt, ch + 1);
         __syncthreads();
@@ -702,13 +702,14 @@ hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStre
     else hipLaunchKernelGGL(tile64_kernel<MODE_GRAM>, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws, 0);
     if (!conj) hipLaunchKernelGGL(tiled_rank1_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws);
     hipLaunchKernelGGL(tiled_clear_kernel, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
+    // Left-looking blocked Cholesky: block row j first receives the updates of ALL earlier block rows in one
+    // pass (every arena tile is read and written once per factorisation, not once per block step), then its
+    // diagonal block is factorised and the rest of the row is solved.
     for (int j = 0; j < NSB; ++j) {
-        hipLaunchKernelGGL(tiled_diag_kernel, dim3(G), dim3(NTHREADS), 0, stream, a, ws, j);
         const int T = NS - 1 - j;
-        if (T > 0) {
-            hipLaunchKernelGGL(tile64_kernel<MODE_TRSM>, xcd_grid(T, G), dim3(NTHREADS), 0, stream, a, ws, j);
-            hipLaunchKernelGGL(tile64_kernel<MODE_SYRK>, xcd_grid(T * (T + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws, j);
-        }
+        if (j > 0) hipLaunchKernelGGL(tile64_kernel<MODE_SYRK>, xcd_grid(T + 1, G), dim3(NTHREADS), 0, stream, a, ws, j);
+        hipLaunchKernelGGL(tiled_diag_kernel, dim3(G), dim3(NTHREADS), 0, stream, a, ws, j);
+        if (T > 0) hipLaunchKernelGGL(tile64_kernel<MODE_TRSM>, xcd_grid(T, G), dim3(NTHREADS), 0, stream, a, ws, j);
     }
     const size_t smem = sizeof(double) * (size_t)(ws.KP + SB);
     hipLaunchKernelGGL(tiled_solve_kernel, dim3(G), dim3(NTHREADS), smem, stream, a, ws);
