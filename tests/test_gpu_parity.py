@@ -229,7 +229,8 @@ def test_tiled_path_matches_reference_golden(native, name, strat):
 @pytest.mark.parametrize("k,N,hf_days,strat", [
     (240, 300, 2, "conjugate"), (255, 300, 2, "conjugate"), (256, 300, 2, "conjugate"), (300, 700, 1, "jeffreys"),
     (319, 250, 3, "conjugate"), (320, 250, 3, "conjugate"), (500, 250, 5, "conjugate"), (511, 260, 5, "conjugate"),
-    (512, 1100, 1, "jeffreys"), (640, 400, 6, "conjugate"), (1000, 500, 22, "conjugate")])
+    (512, 1100, 1, "jeffreys"), (640, 400, 6, "conjugate"), (1000, 500, 22, "conjugate"),
+    (2047, 300, 24, "conjugate")])      # tp_max_assets()
 def test_tiled_path_matches_oracle(native, k, N, hf_days, strat):
     W = 3
     inp = synthetic.make_kernel_inputs(k, N, W, seed=880000 + k, hf_days=hf_days)
