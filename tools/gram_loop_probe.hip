@@ -63,6 +63,51 @@ __global__ void __launch_bounds__(256) probe(double* out, int chunks) {
     out[blockIdx.x * 256 + tid] = s;
 }
 
+// 8 tiles per wave (32 x 64 strip: 2 A fragments x 4 B fragments, 6 LDS reads per 8 MFMAs), 16 staged rows of
+// 192 columns per chunk, 53 KB of LDS -> 3 workgroups per CU
+constexpr int LDX8 = 208;
+template <bool BAR>
+__global__ void __launch_bounds__(256) probe8(double* out, int chunks) {
+    __shared__ double lds[2 * CH * LDX8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    for (int i = tid; i < 2 * CH * LDX8; i += 256) lds[i] = 1.0 + 1e-6 * i;
+    __syncthreads();
+    d4 acc[2][4];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 4; ++b) acc[a][b] = d4{0, 0, 0, 0};
+    for (int ch = 0; ch < chunks; ++ch) {
+        const double* lb = lds + (ch & 1) * CH * LDX8 + fq * LDX8 + fr;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const double a0 = lb[4 * s4 * LDX8 + 32 * wv], a1 = lb[4 * s4 * LDX8 + 32 * wv + 16];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const double bb = lb[4 * s4 * LDX8 + 128 + 16 * b];
+                acc[0][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bb, acc[0][b], 0, 0, 0);
+                acc[1][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bb, acc[1][b], 0, 0, 0);
+            }
+        }
+        if (BAR) __syncthreads();
+    }
+    double s = 0;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 4; ++b) s += acc[a][b][0] + acc[a][b][3];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+template <bool BAR>
+void run8(double* out, int blocks, int chunks, const char* name) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    probe8<BAR><<<blocks, 256>>>(out, chunks);
+    CK(hipEventRecord(e0));
+    probe8<BAR><<<blocks, 256>>>(out, chunks);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double mfma = (double)blocks * 4 * chunks * 32;
+    printf("%-46s %8.3f ms   MFMA pipe %.0f %% (at 2.4 GHz)\n", name, ms, 100 * mfma * 64.0 / (1024.0 * ms * 1e-3 * 2.4e9));
+}
+
 template <int V>
 void run(double* out, int blocks, int chunks, const char* name) {
     hipEvent_t e0, e1;
@@ -87,5 +132,7 @@ int main() {
     run<1>(out, blocks, chunks, "next k-step's reads before the MFMAs, barrier");
     run<2>(out, blocks, chunks, "reads then MFMAs per k-step, no barrier");
     run<3>(out, blocks, chunks, "next k-step's reads before the MFMAs, no barrier");
+    run8<true>(out, 256 * 3 * 8, chunks, "8 tiles per wave, barrier per chunk (3 wg/CU)");
+    run8<false>(out, 256 * 3 * 8, chunks, "8 tiles per wave, no barrier (3 wg/CU)");
     return 0;
 }
