@@ -1052,7 +1052,8 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
 constexpr int tp_min_waves_for_tiles(int) { return TP_MIN_WAVES_PER_SIMD; }
 #else
 constexpr int tp_min_waves_for_tiles(int nt) {
-    return nt <= 5 ? 4 : nt == 6 ? 2 : nt == 7 ? 4 : nt == 8 ? 3 : nt <= 10 ? 2 : nt <= 12 ? 1 : 2;
+    // measured per tile count (tools/sweep_k.py): nt 9: 3 -> +12 % over 2 (k=143); nt 11-12: 2 -> +35 % over 1 (k=175, 191)
+    return nt <= 5 ? 4 : nt == 6 ? 2 : nt == 7 ? 4 : nt <= 9 ? 3 : 2;
 }
 #endif
 
