@@ -1053,7 +1053,7 @@ constexpr int tp_min_waves_for_tiles(int) { return TP_MIN_WAVES_PER_SIMD; }
 #else
 constexpr int tp_min_waves_for_tiles(int nt) {
     // measured per tile count (tools/sweep_k.py): nt 9: 3 -> +12 % over 2 (k=143); nt 11-12: 2 -> +35 % over 1 (k=175, 191)
-    return nt <= 5 ? 4 : nt == 6 ? 2 : nt == 7 ? 4 : nt <= 9 ? 3 : 2;
+    return nt <= 7 ? 4 : nt <= 9 ? 3 : 2;       // nt 6: 4 waves per window at 4 waves/SIMD, +6 % over 2 x 2 (k=95)
 }
 #endif
 
@@ -1116,10 +1116,10 @@ int blocks_per_cu() {
 }  // namespace
 
 
-// wavefronts per workgroup for a tile count: a block row must fit the elimination lanes
-// (16*NT <= 48*NW) and the tiles must fit the register file
+// wavefronts per workgroup for a tile count: the tiles (NT (NT+1)/2 x 8 accumulator registers, spread over the
+// waves) must fit the register file at the occupancy tp_min_waves_for_tiles asks for; measured per tile count
 #ifdef TP_NW_OVERRIDE
 constexpr int tp_waves_for_tiles(int) { return TP_NW_OVERRIDE; }
 #else
-constexpr int tp_waves_for_tiles(int nt) { return nt <= 3 ? 1 : (nt <= 6 ? 2 : (nt <= 12 ? 4 : 8)); }
+constexpr int tp_waves_for_tiles(int nt) { return nt <= 3 ? 1 : (nt <= 5 ? 2 : (nt <= 12 ? 4 : 8)); }
 #endif
