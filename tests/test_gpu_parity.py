@@ -350,3 +350,29 @@ def test_contiguous_layout_with_ragged_rows_and_risk_free_adjustment(native, k, 
     np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(ref).max()))
     if strat == "conjugate":
         np.testing.assert_allclose(aux[:, :6], raux[:, :6], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("k,N,hf_days", [(7, 30, 1), (31, 70, 1), (100, 250, 1), (130, 200, 2), (200, 250, 3), (239, 260, 4),
+                                         (300, 320, 5)])
+def test_layouts_are_bitwise_equivalent(native, k, N, hf_days):
+    """The same windows through the contiguous layout (lean kernel) and through identity row / column index arrays
+    plus a zero risk-free adjustment (generic kernel) give bit-identical weights: the two instantiations (and the
+    tiled path's two Gram kernels) differ in addressing only, never in arithmetic or summation order."""
+    W = 24
+    inp = synthetic.make_kernel_inputs(k, N, W, seed=440000 + k, hf_days=hf_days)
+    n_r, m = inp["n_r"], inp["m"]
+    base = dict(panel=inp["panel"], start=inp["start"], n_r=n_r, hf_panel=inp["hf_panel"], hf_start=inp["hf_start"], m=m,
+                w0=inp["w0"], n0=inp["n0"])
+    rows = (inp["start"][:, None] + np.arange(n_r)[None, :]).astype(np.int32)
+    hrows = (inp["hf_start"][:, None] + np.arange(m)[None, :]).astype(np.int32)
+    idx = dict(panel=inp["panel"], start=None, n_r=n_r, row_idx=rows, col_idx=np.tile(np.arange(k, dtype=np.int32), (W, 1)),
+               rf_adj=np.zeros((W, n_r)), hf_panel=inp["hf_panel"], hf_start=None, hf_row_idx=hrows, m=m, w0=inp["w0"], n0=inp["n0"])
+    w1, s1, a1 = native.posterior_batch("conjugate", k, N, 5.0, **base)
+    w2, s2, a2 = native.posterior_batch("conjugate", k, N, 5.0, **idx)
+    assert (s1 == 0).all() and np.array_equal(s1, s2)
+    assert np.array_equal(w1, w2) and np.array_equal(a1, a2)
+    j1, _, _ = native.posterior_batch("jeffreys", k, N, 5.0, panel=inp["panel"], start=inp["start"], n_r=n_r) if k < n_r - 2 else (None, None, None)
+    if j1 is not None:
+        j2, _, _ = native.posterior_batch("jeffreys", k, N, 5.0, panel=inp["panel"], start=None, n_r=n_r, row_idx=rows,
+                                          col_idx=idx["col_idx"], rf_adj=idx["rf_adj"])
+        assert np.array_equal(j1, j2)
