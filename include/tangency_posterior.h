@@ -138,6 +138,16 @@ int tp_log_returns(tp_handle_t h, const double* prices, int64_t price_rows, int3
  * (ref:1184 -> ref:941) for all rebalancing dates of a backtest at once. */
 int tp_batch_create(tp_handle_t h, const tp_params_t* p, int64_t W, tp_batch_t* out);
 int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in);   /* H2D, synchronous */
+/* The same upload queued on the handle's copy stream and not waited for: with the host arrays in page-locked
+ * memory (tp_host_alloc) the copies of the NEXT batch run under the kernel of the current one (a backtest that
+ * streams batches through tp_batch_run, ref:1232 loop over dates in chunks).  The host arrays must stay valid
+ * until tp_batch_upload_wait returns (or the following tp_batch_run has been synchronised); the next tp_batch_run
+ * of this batch waits for the copies on the device.  Validation of the index arrays still happens in the call. */
+int tp_batch_upload_async(tp_batch_t b, const tp_inputs_t* in);
+int tp_batch_upload_wait(tp_batch_t b);                     /* host wait for the queued copies; sets h2d_ms */
+/* Page-locked host memory for panels and result arrays (hipHostMalloc): DMA at PCIe rate, asynchronous. */
+int tp_host_alloc(void** out, int64_t bytes);
+int tp_host_free(void* p);
 /* Optional right-hand side [W x k] replacing the border column (t for Jeffreys, c S0 w0 + t for the
  * conjugate posterior) in every later tp_batch_run: the weights become (matrix)^-1 rhs / gamma.  NULL
  * restores the default.  Binds the V^-1 1 / V^-1 mu solves of calculate_jorion_portfolio (ref:880-891). */
@@ -148,8 +158,10 @@ int tp_batch_set_rhs(tp_batch_t b, const double* rhs);
  * (ref:924: eta_b S_h = eta_b/2 (I + 1 1'), kappa_h xi_b^2 1 1'), one window per posterior draw. */
 int tp_batch_set_shift(tp_batch_t b, const double* shift);
 int tp_batch_run(tp_batch_t b);                             /* async on the handle's stream; HIP-event timed */
-/* The right-hand side each window was solved for in the last run (default: t = X'1, ref:222, resp.
- * c S0 w0 + t, ref:489); runs the batch once if it has not kept it yet. */
+/* Keep (on != 0) the right-hand side each window is solved for in every later tp_batch_run (default: t = X'1,
+ * ref:222, resp. c S0 w0 + t, ref:489): tp_batch_download_rhs then copies out what the LAST run used.  It never
+ * launches anything itself: without a run after tp_batch_keep_rhs it fails with TP_ERR_INVALID. */
+int tp_batch_keep_rhs(tp_batch_t b, int on);
 int tp_batch_download_rhs(tp_batch_t b, double* rhs_out /* [W x k] */);
 int tp_batch_download(tp_batch_t b, double* weights /* [W x k] */, int32_t* status /* [W] */,
                       double* aux /* optional [W x TP_AUX_STRIDE] */); /* waits for the stream, D2H */
@@ -192,6 +204,14 @@ int tp_last_launch(tp_handle_t h, int* grid, int* block, int* lds_bytes, int* nt
 int tp_comm_unique_id(void* id /* [TP_UNIQUE_ID_BYTES] */);
 int tp_comm_init(tp_handle_t h, const void* id, int rank, int world);
 int tp_comm_destroy(tp_handle_t h);
+int tp_comm_count(tp_handle_t h, int* ranks);              /* ncclCommCount of the handle's communicator */
+/* Single-process form (main.py is ONE process, src/main.py:26): one communicator over the n handles of this
+ * process, rank i = handles[i], one handle per GPU (ncclCommInitAll; no id exchange, no launcher).
+ * tp_group_gather is tp_batch_gather for it: batches[i] on rank i, all with the same W (pad the last shard),
+ * every rank's gather issued in one group by the calling thread; waits; optional host copy-out on the root. */
+int tp_comm_init_all(tp_handle_t* handles, int n);
+int tp_group_gather(tp_batch_t* batches, int n, int root, double* weights_all /* [n x W x k] or NULL */,
+                    int32_t* status_all /* [n x W] or NULL */);
 /* Every rank calls it with the same W_local.  The gathered [world x W x k] weights and [world x W]
  * statuses stay in root's HBM; weights_all / status_all are optional HOST buffers on root (NULL: no
  * copy-out, fetch later with tp_batch_download_gathered). */

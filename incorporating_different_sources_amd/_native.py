@@ -32,9 +32,12 @@ UNIQUE_ID_BYTES = 128
 # every symbol include/tangency_posterior.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTS = [
     "tp_version", "tp_max_assets", "tp_device_count", "tp_create", "tp_destroy", "tp_last_error", "tp_device_info",
-    "tp_log_returns", "tp_batch_create", "tp_batch_upload", "tp_batch_set_rhs", "tp_batch_set_shift", "tp_batch_download_rhs", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1", "tp_batch_download_matrix", "tp_batch_debug_stamps",
-    "tp_batch_destroy", "tp_posterior_batch", "tp_synchronize", "tp_last_timing", "tp_region_begin",
-    "tp_region_end", "tp_last_launch", "tp_comm_unique_id", "tp_comm_init", "tp_comm_destroy",
+    "tp_log_returns", "tp_batch_create", "tp_batch_upload", "tp_batch_upload_async", "tp_batch_upload_wait",
+    "tp_host_alloc", "tp_host_free", "tp_batch_set_rhs", "tp_batch_set_shift", "tp_batch_keep_rhs",
+    "tp_batch_download_rhs", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1", "tp_batch_download_matrix",
+    "tp_batch_debug_stamps", "tp_batch_destroy", "tp_posterior_batch", "tp_synchronize", "tp_last_timing",
+    "tp_region_begin", "tp_region_end", "tp_last_launch", "tp_comm_unique_id", "tp_comm_init", "tp_comm_destroy",
+    "tp_comm_count", "tp_comm_init_all", "tp_group_gather",
     "tp_batch_gather", "tp_batch_gather_async", "tp_batch_download_gathered",
 ]
 
@@ -78,6 +81,14 @@ def _load():
                                    c_int64, POINTER(c_double)]
     lib.tp_batch_create.argtypes = [c_void_p, POINTER(tp_params_t), c_int64, POINTER(c_void_p)]
     lib.tp_batch_upload.argtypes = [c_void_p, POINTER(tp_inputs_t)]
+    lib.tp_batch_upload_async.argtypes = [c_void_p, POINTER(tp_inputs_t)]
+    lib.tp_batch_upload_wait.argtypes = [c_void_p]
+    lib.tp_host_alloc.argtypes = [POINTER(c_void_p), c_int64]
+    lib.tp_host_free.argtypes = [c_void_p]
+    lib.tp_batch_keep_rhs.argtypes = [c_void_p, c_int]
+    lib.tp_comm_count.argtypes = [c_void_p, POINTER(c_int)]
+    lib.tp_comm_init_all.argtypes = [POINTER(c_void_p), c_int]
+    lib.tp_group_gather.argtypes = [POINTER(c_void_p), c_int, c_int, POINTER(c_double), POINTER(c_int32)]
     lib.tp_batch_set_rhs.argtypes = [c_void_p, POINTER(c_double)]
     lib.tp_batch_set_shift.argtypes = [c_void_p, POINTER(c_double)]
     lib.tp_batch_download_rhs.argtypes = [c_void_p, POINTER(c_double)]
@@ -133,6 +144,46 @@ def _arr(a, dtype, shape=None, name=""):
     if shape is not None and tuple(a.shape) != tuple(shape):
         raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(a.shape)}")
     return a
+
+
+class _PinnedBlock:
+    """Owner of one tp_host_alloc block; numpy arrays made over it keep it alive through `.base`."""
+
+    def __init__(self, nbytes: int):
+        self.ptr = c_void_p()
+        rc = lib.tp_host_alloc(ctypes.byref(self.ptr), int(nbytes))
+        if rc != TP_OK:
+            raise TangencyError(rc, f"tp_host_alloc({nbytes}) failed")
+        self.nbytes = int(nbytes)
+        self.buf = (ctypes.c_char * max(1, self.nbytes)).from_address(self.ptr.value)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib.tp_host_free(self.ptr)
+                self.ptr = c_void_p()
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
+    """An uninitialised array in page-locked host memory (`tp_host_alloc`): uploads from it and downloads into it
+    run at PCIe rate and, with `Batch.upload_async`, without blocking the host."""
+    dtype = np.dtype(dtype)
+    shape = (shape,) if np.isscalar(shape) else tuple(shape)
+    n = int(np.prod(shape)) if shape else 1
+    block = _PinnedBlock(n * dtype.itemsize)
+    arr = np.frombuffer(block.buf, dtype=dtype, count=n).reshape(shape)
+    # np.frombuffer keeps `block.buf` (and through a reference cycle-free attribute the block) alive
+    block.buf._owner = block
+    return arr
+
+
+def pinned_copy(a) -> np.ndarray:
+    a = np.asarray(a)
+    out = pinned_empty(a.shape, a.dtype)
+    out[...] = a
+    return out
 
 
 class Device:
@@ -206,6 +257,12 @@ class Device:
     def comm_destroy(self):
         self._check(lib.tp_comm_destroy(self._h))
 
+    def comm_count(self) -> int:
+        """Ranks of the handle's RCCL communicator (ncclCommCount)."""
+        n = c_int()
+        self._check(lib.tp_comm_count(self._h, ctypes.byref(n)))
+        return n.value
+
     # ---- price front-end ----------------------------------------------------------------------
     def log_returns(self, prices, num, den) -> np.ndarray:
         """out[i] = log(prices[num[i]] / prices[den[i]]) on the device (NaN -> 0), ref:44 / ref:311."""
@@ -250,7 +307,7 @@ class Batch:
 
     def upload(self, panel, start=None, hf_panel=None, hf_start=None, w0=None, n0=None, row_idx=None,
                n_rows=None, col_idx=None, rf_adj=None, hf_row_idx=None, hf_count=None, ret_pairs=None,
-               hf_ret_pairs=None):
+               hf_ret_pairs=None, asynchronous=False):
         """H2D.  `ret_pairs=(num, den)`: `panel` holds PRICES and the device forms the log-return panel
         R[i] = log(P[num[i]] / P[den[i]]) that start / row_idx address; `hf_ret_pairs` likewise for `hf_panel`."""
         W, k, n_r, m = self.W, self.k, self.n_r, self.m
@@ -286,9 +343,27 @@ class Batch:
             _ptr(a["ret_num"], c_int32), _ptr(a["ret_den"], c_int32), a["ret_num"].size if a["ret_num"] is not None else 0,
             _ptr(a["hf_ret_num"], c_int32), _ptr(a["hf_ret_den"], c_int32),
             a["hf_ret_num"].size if a["hf_ret_num"] is not None else 0)
-        self._keep = a     # host arrays stay alive for the duration of the (synchronous) upload
-        self.dev._check(lib.tp_batch_upload(self._b, ctypes.byref(inp)))
+        self._keep = a     # host arrays stay alive for the duration of the upload
+        if asynchronous:
+            self.dev._check(lib.tp_batch_upload_async(self._b, ctypes.byref(inp)))   # `upload_wait` releases them
+        else:
+            self.dev._check(lib.tp_batch_upload(self._b, ctypes.byref(inp)))
+            self._keep = None
+        return self
+
+    def upload_async(self, panel, **kw):
+        """`upload` queued on the device's copy stream and not waited for (arrays from `pinned_empty` make the
+        copies truly asynchronous).  The next `run` waits for them on the device; `upload_wait` on the host."""
+        return self.upload(panel, asynchronous=True, **kw)
+
+    def upload_wait(self):
+        self.dev._check(lib.tp_batch_upload_wait(self._b))
         self._keep = None
+        return self
+
+    def keep_rhs(self, on=True):
+        """Keep the right-hand side every window is solved for in later runs (`download_rhs` reads the last run's)."""
+        self.dev._check(lib.tp_batch_keep_rhs(self._b, 1 if on else 0))
         return self
 
     def set_rhs(self, rhs):
@@ -304,7 +379,8 @@ class Batch:
         return self
 
     def download_rhs(self) -> np.ndarray:
-        """[W x k] right-hand sides the windows were solved for (t = X'1 by default)."""
+        """[W x k] right-hand sides the windows were solved for in the last run (t = X'1 by default); needs
+        `keep_rhs()` before that run."""
         out = np.empty((self.W, self.k), dtype=np.float64)
         self.dev._check(lib.tp_batch_download_rhs(self._b, _ptr(out, c_double)))
         return out
@@ -313,7 +389,20 @@ class Batch:
         self.dev._check(lib.tp_batch_run(self._b))
         return self
 
-    def download(self, want_aux=True):
+    def download(self, want_aux=True, out=None):
+        """(weights, status, aux).  `out=(weights, status[, aux])`: write into these arrays (e.g. `pinned_empty`)."""
+        if out is not None:
+            weights, status = out[0], out[1]
+            aux = out[2] if len(out) > 2 else None
+            if weights.shape != (self.W, self.k) or weights.dtype != np.float64 or not weights.flags.c_contiguous:
+                raise ValueError("out[0]: C-contiguous float64 [W x k] expected")
+            if status.shape != (self.W,) or status.dtype != np.int32:
+                raise ValueError("out[1]: int32 [W] expected")
+            if aux is not None and (aux.shape != (self.W, AUX_STRIDE) or aux.dtype != np.float64):
+                raise ValueError("out[2]: float64 [W x 8] expected")
+            self.dev._check(lib.tp_batch_download(self._b, _ptr(weights, c_double), _ptr(status, c_int32),
+                                                  _ptr(aux, c_double)))
+            return weights, status, aux
         weights = np.empty((self.W, self.k), dtype=np.float64)
         status = np.empty(self.W, dtype=np.int32)
         aux = np.empty((self.W, AUX_STRIDE), dtype=np.float64) if want_aux else None
@@ -369,7 +458,61 @@ class Batch:
         return wall, sall
 
 
+class DeviceGroup:
+    """Every visible GPU of THIS process under one RCCL communicator (`tp_comm_init_all`): the single-process
+    multi-device mode behind `backtest_portfolio` (the reference's main.py is one process, src/main.py:26).
+    Windows shard contiguously over the devices (`shard.run_sharded`); one grouped gather brings the weights to
+    device 0."""
+
+    def __init__(self, device_ids=None):
+        ids = list(range(device_count())) if device_ids is None else list(device_ids)
+        if not ids:
+            raise TangencyError(TP_ERR_NO_DEVICE, "no HIP device available; there is no CPU fallback")
+        self.devices = [Device(i) for i in ids]
+        self.world = len(self.devices)
+        if self.world > 1:
+            arr = (c_void_p * self.world)(*[d._h for d in self.devices])
+            rc = lib.tp_comm_init_all(arr, self.world)
+            if rc != TP_OK:
+                raise TangencyError(rc, lib.tp_last_error(self.devices[0]._h).decode())
+            for r, d in enumerate(self.devices):
+                d.rank, d.world = r, self.world
+
+    def gather(self, batches, root=0):
+        """One grouped RCCL gather of the equally sized batches (batches[i] on devices[i]) to `root`: returns
+        (weights [world x W x k], status [world x W]) on the host."""
+        n = len(batches)
+        if n != self.world:
+            raise ValueError("one batch per device expected")
+        if n == 1:
+            w, s, _ = batches[0].download(want_aux=False)
+            return w[None], s[None]
+        W, k = batches[0].W, batches[0].k
+        wall = np.empty((n, W, k), dtype=np.float64)
+        sall = np.empty((n, W), dtype=np.int32)
+        arr = (c_void_p * n)(*[b._b for b in batches])
+        rc = lib.tp_group_gather(arr, n, int(root), _ptr(wall, c_double), _ptr(sall, c_int32))
+        if rc != TP_OK:
+            raise TangencyError(rc, lib.tp_last_error(self.devices[root]._h).decode())
+        return wall, sall
+
+    def close(self):
+        for d in self.devices:
+            d.close()
+        self.devices = []
+
+
 _default_device = None
+_default_group = None
+
+
+def default_group() -> DeviceGroup:
+    """All visible GPUs of this process (created on first use; `TP_DEVICES=0,1,..` restricts them)."""
+    global _default_group
+    if _default_group is None:
+        ids = os.environ.get("TP_DEVICES")
+        _default_group = DeviceGroup([int(x) for x in ids.split(",")] if ids else None)
+    return _default_group
 
 
 def default_device() -> Device:

@@ -109,34 +109,48 @@ class MarketPanels:
         if len(self.base) > 1:
             self.L_nan[1:] = _return_is_nan(self.base[1:], self.base[:-1])
         self._mcm = {}
+        self.weights_cache = {}        # (spec key, dates) -> device results, filled by cross-spec batches
 
     # -- market-condition metric (ref:90-114, 247-267) --------------------------------------------
     def mcm(self, market_data, key):
-        if key not in self._mcm:
-            frame = market_data[key].sort_index()
+        src = market_data[key]
+        hit = self._mcm.get(key)
+        if hit is None or hit["frame"] is not src:      # a replaced VIX / EPU frame must not reuse the old arrays
+            frame = src.sort_index()
             vals = frame.to_numpy(dtype=np.float64).reshape(len(frame), -1)[:, 0]
             entry = dict(ns=_ns(frame.index), vals=vals)
             if self.frequency != "daily":
                 R = _resample_last(frame, self.frequency)
                 entry["rvals"] = R.to_numpy(dtype=np.float64).reshape(len(R), -1)[:, 0]
                 entry["rlabel_ns"] = _ns(R.index)
+            entry["frame"] = src
             self._mcm[key] = entry
         return self._mcm[key]
 
 
 _PANEL_CACHE = {}
+_PANEL_FRAMES = ("stock_prices_df", "stock_intraday_prices_df", "stock_market_caps_df", "risk_free_rate_df")
 
 
 def panels_for(market_data, frequency) -> MarketPanels:
-    key = (id(market_data["stock_prices_df"]), id(market_data["stock_intraday_prices_df"]),
-           id(market_data["stock_market_caps_df"]), id(market_data["risk_free_rate_df"]), frequency)
+    """The numpy panels of `market_data`, cached per (frames, frequency).  The cache entry holds a reference to
+    EVERY frame it was built from and is valid only while `market_data` still holds those very objects (an `id()`
+    alone could be recycled by a new frame).  Frames must not be edited in place between calls - replace them, or
+    call `clear_panel_cache()`."""
+    frames = tuple(market_data[name] for name in _PANEL_FRAMES)
+    key = tuple(id(f) for f in frames) + (frequency,)
     hit = _PANEL_CACHE.get(key)
-    if hit is None or hit[0] is not market_data["stock_prices_df"]:
+    if hit is None or any(a is not b for a, b in zip(hit[0], frames)):
         if len(_PANEL_CACHE) > 8:
             _PANEL_CACHE.clear()
-        hit = (market_data["stock_prices_df"], MarketPanels(market_data, frequency))
+        hit = (frames, MarketPanels(market_data, frequency))
         _PANEL_CACHE[key] = hit
     return hit[1]
+
+
+def clear_panel_cache():
+    """Forget every cached panel (and the weights cached with them), e.g. after editing a frame in place."""
+    _PANEL_CACHE.clear()
 
 
 def _mean_gap_and_check(label_ns):
@@ -170,6 +184,70 @@ def select_universe(mp: MarketPanels, pos, size, window_days, rebal_frequency, m
     return order.astype(np.int32), caps[order]
 
 
+def pack_universes(trading_dates, portfolio_spec, market_data, members_of=None):
+    """Universe selection only (ref:953-988): (column indices [W x k], labels, market caps [W x k]) per date.
+    What the passive strategies vw / ew need - the reference touches neither returns nor the risk-free rate for
+    them (ref:990-997), so none of the estimator-only conditions (date gaps, NaN risk-free days, intraday bars of
+    the window) may stop them."""
+    freq = portfolio_spec["rolling_window_frequency"]
+    N, k = portfolio_spec["rolling_window"], portfolio_spec["size"]
+    mp = panels_for(market_data, freq)
+    window_days = N * _TRADING_DAYS[freq]
+    W, K = len(trading_dates), len(mp.tickers)
+    col_idx = np.zeros((W, k), dtype=np.int32)
+    caps_all = np.zeros((W, k), dtype=np.float64)
+    labels = []
+    all_members = np.ones(K, dtype=bool)
+    for w, ts in enumerate(trading_dates):
+        pos, members = _date_position_and_members(mp, ts, members_of, all_members)
+        cols, caps = select_universe(mp, pos, k, window_days, portfolio_spec["rebalancing_frequency"], members)
+        if len(cols) != k:
+            raise ValueError(f"universe has {len(cols)} assets, portfolio_spec['size'] is {k}")
+        col_idx[w], caps_all[w] = cols, caps
+        labels.append([mp.tickers[c] for c in cols])
+        lo_row = max(0, pos + 1 - window_days)                     # ref:986-988
+        if np.isnan(mp.P[lo_row:pos + 1][:, cols]).any():
+            logger.error("Found NA values in the filtered stock prices.")
+            raise ValueError("The filtered stock prices contain NA values.")
+    return col_idx, labels, caps_all
+
+
+def _date_position_and_members(mp, ts, members_of, all_members):
+    d = pd.Timestamp(ts).value
+    pos = int(np.searchsorted(mp.date_ns, d))
+    if pos >= len(mp.date_ns) or mp.date_ns[pos] != d:
+        raise ValueError(f"trading_date_ts {ts} must be the last date in the DataFrame.")
+    members = all_members
+    if members_of is not None:
+        tick = members_of(ts)
+        if tick is not None:
+            ts_set = set(tick)
+            members = np.array([t in ts_set for t in mp.tickers])
+    return pos, members
+
+
+def prior_inputs(trading_dates, portfolio_spec, market_data, caps):
+    """(w0 [W x k], n0 [W]) of a conjugate spec for dates whose universes (market caps `caps`, cap-descending) are
+    already selected: what differs between the conjugate specs of one grid (ref:361-380 vw / ew, ref:247-267 VIX /
+    EPU and mcm_scaling), so that several specs can share ONE packed batch."""
+    strategy = portfolio_spec["weighting_strategy"]
+    freq = portfolio_spec["rolling_window_frequency"]
+    N, k = portfolio_spec["rolling_window"], portfolio_spec["size"]
+    mp = panels_for(market_data, freq)
+    mcm = mp.mcm(market_data, "vix_prices_df" if "_vix_" in strategy else "epu_prices_df")
+    caps = np.asarray(caps, dtype=np.float64)
+    if "vw" in strategy:
+        w0 = caps / caps.sum(axis=1, keepdims=True)                  # ref:692-695 (already cap-descending)
+    elif "ew" in strategy:
+        w0 = np.full(caps.shape, 1 / k)                              # ref:670-672
+    else:
+        logger.error("Unknown conjugate portfolio prior weights.")
+        raise ValueError("Unknown conjugate portfolio prior weights.")
+    n0 = np.array([_prior_strength(mp, mcm, pd.Timestamp(ts).value, ts, N, portfolio_spec["mcm_scaling"])
+                   for ts in trading_dates], dtype=np.float64)
+    return w0, n0
+
+
 def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None, return_caps=False):
     """All rebalancing dates of one spec -> keyword arguments of `_native.posterior_batch` plus the
     per-window ticker labels (and, with `return_caps`, the market caps [W x k] of the selected assets in the
@@ -201,15 +279,7 @@ def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None, re
 
     for w, ts in enumerate(trading_dates):
         d = pd.Timestamp(ts).value
-        pos = int(np.searchsorted(mp.date_ns, d))
-        if pos >= len(mp.date_ns) or mp.date_ns[pos] != d:
-            raise ValueError(f"trading_date_ts {ts} must be the last date in the DataFrame.")
-        members = all_members
-        if members_of is not None:
-            tick = members_of(ts)
-            if tick is not None:
-                ts_set = set(tick)
-                members = np.array([t in ts_set for t in mp.tickers])
+        pos, members = _date_position_and_members(mp, ts, members_of, all_members)
         cols, caps = select_universe(mp, pos, k, window_days, portfolio_spec["rebalancing_frequency"], members)
         if len(cols) != k:
             raise ValueError(f"universe has {len(cols)} assets, portfolio_spec['size'] is {k}")

@@ -99,7 +99,13 @@ struct Cfg {
     static constexpr int OFF_DIAG = OFF_WVEC + KP;       // 2 x [16][16] diagonal tile handed to the eliminating wave
     static constexpr int OFF_SCAL = OFF_DIAG + 512;      // [8] scalars: 0 = z'z, 1 = not-positive-definite flag
     static constexpr int OFF_COFF = OFF_SCAL + 8;        // [KP] uint32: byte offsets 8*col_idx[c] of the gathered columns
-    static constexpr int LDS_DOUBLES = OFF_COFF + KP / 2;
+    // [16][16] identity tile: the eliminating wave loads [A_jj | I] with ONE address select.  During the
+    // factorisation the partial-product area of the back substitution is free and holds it when it is large
+    // enough (NT >= 6; NT = 7 sits at the 40 KiB limit of 4 workgroups per CU), else it gets space of its own.
+    static constexpr int IDT_DOUBLES = 256;              // identity tile only; lanes >= 32 re-read it (their values are never used)
+    static constexpr bool IDT_IN_PART = NTILES * 16 >= IDT_DOUBLES;
+    static constexpr int OFF_IDT = IDT_IN_PART ? OFF_PART : OFF_COFF + KP / 2;
+    static constexpr int LDS_DOUBLES = OFF_COFF + KP / 2 + (IDT_IN_PART ? 0 : IDT_DOUBLES);
     static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
 };
 
@@ -155,6 +161,16 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
     e = fma(-(d * y), y, 1.0);
     y = fma(0.5 * y, e, y);
     return y;
+}
+
+// 1/sqrt(d) from the v_rsq_f64 seed (23 good bits) by ONE third-order step, y (1 + e/2 + 3 e^2/8) with
+// e = 1 - d y^2: the error term is O(e^3) ~ 2^-68.  Six instructions on a chain of five (rsqrt_nr: nine on
+// seven) - the pivot chain of the factorisation pays for both.
+__device__ __forceinline__ double rsqrt_cubic(double d) {
+    const double y = __builtin_amdgcn_rsq(d);
+    const double e = fma(-(d * y), y, 1.0);
+    const double u = fma(e, 0.375, 0.5);
+    return fma(y * e, u, y);
 }
 
 __device__ __forceinline__ double wave_sum64(double v) {
@@ -810,6 +826,8 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
     // R_jJ = M A_jJ by MFMA - the accumulator registers ARE the B operand - and goes to LDS;
     // (4) the trailing tiles are updated from that LDS image by MFMA.  The border column of block row
     // j turns into y_j = (R^-T b)_j on the way: the forward substitution costs nothing extra.
+    for (int i = tid0; i < C::IDT_DOUBLES; i += C::NTHREADS)      // identity tile of the elimination (published by the
+        lds[C::OFF_IDT + i] = ((i >> 4) == (i & 15)) ? 1.0 : 0.0;  // barrier of block step 0)
     double* RB = lds + C::OFF_STAGE0;          // block row j of R, [16][LDX]
     double* MB = lds + C::OFF_STAGE1;          // M_j transposed, [NTB][16][16]: MB[j][c][i] = M_j[i][c]
 #ifdef TP_STAMP
@@ -849,21 +867,24 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
             __builtin_amdgcn_s_setprio(3);
             const int c16 = lane & 15;
             double a[16];
+            // lanes 0-15: the tile's columns; lanes 16-31: the identity's (lanes 32-63 repeat them, unused).  One
+            // select on the base, 16 reads at immediate offsets (the obvious `lane < 16 ? DG[..] : (c16 == i)` was
+            // compiled into 16 divergent branches with a serialised LDS read each).
+            const double* src = (lane < 16) ? DG : (lds + C::OFF_IDT);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const double x = DG[i * 16 + c16];
-                a[i] = (lane < 16) ? x : ((lane < 32 && c16 == i) ? 1.0 : 0.0);
-            }
+            for (int i = 0; i < 16; ++i) a[i] = src[i * 16 + c16];
             bool bad = false;
-            // The pivot loop is ISSUE-bound, not latency-bound: one wavefront issues an fp64 VALU
-            // operation every ~8 cycles and each multiplier costs 2 v_readlane + 1 FMA, so what counts
-            // is the instruction count (measured: a square-root-free variant with a shorter dependent
-            // chain but one more multiply per multiplier was 8 % slower).  Look-ahead: as soon as pivot
-            // p has updated row p+1 the next pivot's rsqrt (v_rsq_f64 + 2 Newton steps) is started, so
-            // it overlaps the remaining row updates of pivot p.
+            // The pivot loop is ISSUE-bound, not latency-bound, and what it is bound by is its count of vector
+            // instructions: 2 v_readlane + 1 v_fma_f64 per multiplier, ~12 cycles each on a SIMD shared with three
+            // other windows' MFMA streams (in-kernel stamps: 7.5 k cycles per 16 x 16 tile).  Measured in round 2,
+            // all slower: multipliers by fp64 DPP (v_fmac_f64 row_newbcast, 440 instead of 615 instructions per
+            // tile: +2 %, the fp64 DPP forms issue slowly); a square-root-free scalar pivot chain of 6 dependent steps
+            // with the row updates interleaved between the steps (DPP: +25 % in this phase; v_readlane pairs:
+            // +33 %, 840 instructions).  Look-ahead: as soon as pivot p has updated row p+1 the next pivot's rsqrt
+            // (v_rsq_f64 + one cubic step) is started, so it overlaps the remaining row updates of pivot p.
             double d0 = readlane_d(a[0], 0);
             bad |= !(d0 > 0.0);
-            double rinv = rsqrt_nr(d0);
+            double rinv = rsqrt_cubic(d0);
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
                 if (p < npiv) {                 // wave-uniform: the last block row stops at its last real pivot
@@ -876,7 +897,7 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
                         const bool live = p + 1 < npiv;
                         bad |= live && !(dn > 0.0);
                         dn = live ? dn : 1.0;
-                        rinv_next = rsqrt_nr(dn);
+                        rinv_next = rsqrt_cubic(dn);
                     }
 #pragma unroll
                     for (int i = p + 2; i < 16; ++i) {

@@ -38,6 +38,11 @@ struct tp_handle_s {
     // overlapped gather (tp_batch_gather_async): its own high-priority stream next to the kernel stream
     hipStream_t comm_stream = nullptr;
     hipEvent_t cg0 = nullptr, cg1 = nullptr;
+    // asynchronous uploads (tp_batch_upload_async): a copy stream of their own, so that the H2D copies of the next
+    // batch run under the kernel of the current one
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t cp0 = nullptr, cp1 = nullptr;
+    bool copy_timed = false;
     bool gather_timed = false;
     tp_batch_t deferred = nullptr;  // batch whose tp_batch_gather_async is requested but not yet on the gather stream      // cg0/cg1 bracket the last asynchronous gather and have not been read yet
 };
@@ -54,10 +59,15 @@ struct tp_batch_s {
     int panel_ld = 0, hf_ld = 0;
     DevBuf panel, start, row_idx, n_rows, col_idx, rf_adj, hf_panel, hf_start, hf_row_idx, hf_count, w0, n0;
     DevBuf weights, status, aux, dbg, gather_w, gather_s, weights2, status2, stamps, rhs, out_rhs, shift;
+    DevBuf fe_prices, fe_num, fe_den, fe_hf_prices, fe_hf_num, fe_hf_den;   // price front-end staging (freed after a synchronous upload)
     DevBuf t_arena, t_rinv, t_ybar, t_zc, t_scal, t_flags;   // large-k path workspace
     int64_t tiled_capacity = 0;                               // windows in flight per sub-batch
     bool uploaded = false;
     bool gathered = false;
+    bool rhs_valid = false;                          // out_rhs was allocated before the last run (tp_batch_keep_rhs)
+    hipEvent_t ran = nullptr;                        // end of this batch's last launch (recorded once asynchronous uploads are in use)
+    hipEvent_t upload_done = nullptr;                // tp_batch_upload_async: end of the copies on the copy stream
+    bool upload_pending = false;
     // tp_batch_gather_async: results alternate between (weights, status) and (weights2, status2), so that the
     // gather of run i reads one pair while run i+1 writes the other; run i+2 waits for that gather's event
     bool pingpong = false;
@@ -97,14 +107,14 @@ int ensure(tp_handle_t h, DevBuf& b, size_t bytes) {
     return TP_OK;
 }
 
-int put(tp_handle_t h, DevBuf& b, const void* src, size_t bytes) {
+int put(tp_handle_t h, DevBuf& b, const void* src, size_t bytes, hipStream_t st = nullptr) {
     if (!src) {   // optional input absent: drop any stale copy
         if (b.p) { HIP_TRY(h, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
         return TP_OK;
     }
     int rc = ensure(h, b, bytes);
     if (rc != TP_OK) return rc;
-    HIP_TRY(h, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st ? st : h->stream));
     return TP_OK;
 }
 
@@ -234,9 +244,9 @@ int validate_inputs(tp_handle_t h, const tp_params_t& p, int64_t W, const tp_inp
                 if (row < 0 || row >= in->panel_rows)
                     return fail(h, TP_ERR_INVALID, "row_idx[%lld][%d]=%lld outside the panel", (long long)w, r, (long long)row);
             }
-        } else if (in->start[w] < 0 || in->start[w] + nr > in->panel_rows) {
-            return fail(h, TP_ERR_INVALID, "window %lld rows [%lld,%lld) outside the panel (%lld rows)", (long long)w,
-                        (long long)in->start[w], (long long)(in->start[w] + nr), (long long)in->panel_rows);
+        } else if (nr > in->panel_rows || in->start[w] < 0 || in->start[w] > in->panel_rows - nr) {   // no start + nr: it may overflow
+            return fail(h, TP_ERR_INVALID, "window %lld: %d rows from row %lld lie outside the panel (%lld rows)", (long long)w,
+                        nr, (long long)in->start[w], (long long)in->panel_rows);
         }
         if (in->col_idx) {
             for (int j = 0; j < p.k; ++j) {
@@ -254,9 +264,9 @@ int validate_inputs(tp_handle_t h, const tp_params_t& p, int64_t W, const tp_inp
                     if (row < 0 || row >= in->hf_rows)
                         return fail(h, TP_ERR_INVALID, "hf_row_idx[%lld][%d]=%lld outside the panel", (long long)w, r, (long long)row);
                 }
-            } else if (in->hf_start[w] < 0 || in->hf_start[w] + mm > in->hf_rows) {
-                return fail(h, TP_ERR_INVALID, "window %lld intraday rows [%lld,%lld) outside the panel (%lld rows)",
-                            (long long)w, (long long)in->hf_start[w], (long long)(in->hf_start[w] + mm), (long long)in->hf_rows);
+            } else if (mm > in->hf_rows || in->hf_start[w] < 0 || in->hf_start[w] > in->hf_rows - mm) {
+                return fail(h, TP_ERR_INVALID, "window %lld: %d intraday rows from row %lld lie outside the panel (%lld rows)",
+                            (long long)w, mm, (long long)in->hf_start[w], (long long)in->hf_rows);
             }
         }
     }
@@ -325,7 +335,7 @@ static int flush_gather(tp_handle_t h);
 
 extern "C" {
 
-const char* tp_version(void) { return "tangency-posterior 0.2.0 (gfx950, fp64 MFMA: register-tile kernel k<=239, tiled pipeline k<=2047)"; }
+const char* tp_version(void) { return "tangency-posterior 0.3.0 (gfx950, fp64 MFMA: register-tile kernel k<=239, tiled pipeline k<=2047)"; }
 
 int tp_max_assets(void) { return tp_tiled_max_assets(); }
 
@@ -378,6 +388,9 @@ int tp_destroy(tp_handle_t h) {
     for (hipEvent_t e : {h->cg0, h->cg1})
         if (e) (void)hipEventDestroy(e);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    for (hipEvent_t e : {h->cp0, h->cp1})
+        if (e) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->reg0) (void)hipEventDestroy(h->reg0);
@@ -445,12 +458,18 @@ int tp_batch_create(tp_handle_t h, const tp_params_t* p, int64_t W, tp_batch_t* 
 int tp_batch_destroy(tp_batch_t b) {
     if (!b) return TP_OK;
     (void)hipSetDevice(b->h->device);
+    // A gather that was requested (tp_batch_gather_async) but not yet put on its stream is a collective the peer
+    // ranks may already be waiting in: issue it before the buffers go away - dropping it would hang them.
+    if (b->h->deferred == b) (void)flush_gather(b->h);
     (void)hipStreamSynchronize(b->h->stream);
     if (b->h->comm_stream) (void)hipStreamSynchronize(b->h->comm_stream);   // a gather may still read the results
     if (b->h->deferred == b) b->h->deferred = nullptr;
     for (hipEvent_t e : b->gather_done)
         if (e) (void)hipEventDestroy(e);
     if (b->snap) (void)hipEventDestroy(b->snap);
+    if (b->upload_done) { (void)hipEventSynchronize(b->upload_done); (void)hipEventDestroy(b->upload_done); }
+    if (b->ran) (void)hipEventDestroy(b->ran);
+    for (DevBuf* d : {&b->fe_prices, &b->fe_num, &b->fe_den, &b->fe_hf_prices, &b->fe_hf_num, &b->fe_hf_den}) release(*d);
     DevBuf* all[] = {&b->panel, &b->start, &b->row_idx, &b->n_rows, &b->col_idx, &b->rf_adj, &b->hf_panel, &b->hf_start,
                      &b->hf_row_idx, &b->hf_count, &b->w0, &b->n0, &b->weights, &b->status, &b->aux, &b->dbg,
                      &b->gather_w, &b->gather_s, &b->weights2, &b->status2, &b->stamps, &b->rhs, &b->out_rhs, &b->shift, &b->t_arena, &b->t_rinv, &b->t_ybar, &b->t_zc,
@@ -460,8 +479,9 @@ int tp_batch_destroy(tp_batch_t b) {
     return TP_OK;
 }
 
-int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in) {
-    if (!b) return TP_ERR_INVALID;
+// H2D of one batch on stream `st`.  wait = true: the synchronous form (tp_batch_upload) on the kernel stream;
+// wait = false: copies are only queued (pinned host memory makes them truly asynchronous), upload_done marks their end.
+static int upload_common(tp_batch_t b, const tp_inputs_t* in, hipStream_t st, bool wait) {
     tp_handle_t h = b->h;
     const tp_params_t& p = b->p;
     const int64_t W = b->W;
@@ -469,26 +489,36 @@ int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in) {
     if (rc != TP_OK) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     const bool conj = p.strategy == TP_STRATEGY_CONJUGATE;
-    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    h->kernel_timed = false;
-#define PUT(buf, ptr, bytes) do { rc = put(h, b->buf, (ptr), (bytes)); if (rc != TP_OK) return rc; } while (0)
+    // a launch of THIS batch that is still running reads the buffers about to be overwritten: the copy stream waits
+    // for it (other batches' launches on the kernel stream are what the copies are meant to run under)
+    if (!wait && b->ran) HIP_TRY(h, hipStreamWaitEvent(st, b->ran, 0));
+    hipEvent_t e0 = wait ? h->ev0 : h->cp0, e1 = wait ? h->ev1 : h->cp1;
+    if (!wait && h->copy_timed) {     // read the previous asynchronous upload's span before its events are reused
+        HIP_TRY(h, hipEventSynchronize(h->cp1));
+        float ms0 = 0;
+        HIP_TRY(h, hipEventElapsedTime(&ms0, h->cp0, h->cp1));
+        h->h2d_ms = ms0;
+        h->copy_timed = false;
+    }
+    HIP_TRY(h, hipEventRecord(e0, st));
+    if (wait) h->kernel_timed = false;
+#define PUT(buf, ptr, bytes) do { rc = put(h, b->buf, (ptr), (bytes), st); if (rc != TP_OK) return rc; } while (0)
     // panels: log-returns as given, or formed on the device from prices (returns_frontend.hip)
-    ScratchBuf prices, pnum, pden;       // price staging of the front-end
-    auto panel_in = [&](DevBuf& dst, const double* src, int64_t rows, int ld, const int32_t* num, const int32_t* den,
-                        int64_t n_out) -> int {
-        if (!num) return put(h, dst, src, sizeof(double) * (size_t)rows * ld);
-        int r = put(h, prices, src, sizeof(double) * (size_t)rows * ld);
-        if (r == TP_OK) r = put(h, pnum, num, sizeof(int32_t) * (size_t)n_out);
-        if (r == TP_OK) r = put(h, pden, den, sizeof(int32_t) * (size_t)n_out);
+    auto panel_in = [&](DevBuf& dst, DevBuf& prices, DevBuf& pnum, DevBuf& pden, const double* src, int64_t rows, int ld,
+                        const int32_t* num, const int32_t* den, int64_t n_out) -> int {
+        if (!num) return put(h, dst, src, sizeof(double) * (size_t)rows * ld, st);
+        int r = put(h, prices, src, sizeof(double) * (size_t)rows * ld, st);
+        if (r == TP_OK) r = put(h, pnum, num, sizeof(int32_t) * (size_t)n_out, st);
+        if (r == TP_OK) r = put(h, pden, den, sizeof(int32_t) * (size_t)n_out, st);
         if (r == TP_OK) r = ensure(h, dst, sizeof(double) * (size_t)n_out * ld);
         if (r != TP_OK) return r;
         hipError_t e = tp_log_return_rows_launch((const double*)prices.p, ld, (const int*)pnum.p, (const int*)pden.p,
-                                                 (long long)n_out, (double*)dst.p, h->stream);
+                                                 (long long)n_out, (double*)dst.p, st);
         if (e != hipSuccess) return fail(h, TP_ERR_HIP, "log-return kernel launch failed: %s", hipGetErrorString(e));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));      // the staging buffers are reused / freed next
         return TP_OK;
     };
-    rc = panel_in(b->panel, in->panel, in->panel_rows, in->panel_ld, in->ret_num, in->ret_den, in->ret_rows);
+    rc = panel_in(b->panel, b->fe_prices, b->fe_num, b->fe_den, in->panel, in->panel_rows, in->panel_ld, in->ret_num,
+                  in->ret_den, in->ret_rows);
     if (rc != TP_OK) return rc;
     PUT(start, in->start, sizeof(int64_t) * (size_t)W);
     PUT(row_idx, in->row_idx, sizeof(int32_t) * (size_t)W * p.n_r);
@@ -496,7 +526,8 @@ int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in) {
     PUT(col_idx, in->col_idx, sizeof(int32_t) * (size_t)W * p.k);
     PUT(rf_adj, in->rf_adj, sizeof(double) * (size_t)W * p.n_r);
     if (conj) {
-        rc = panel_in(b->hf_panel, in->hf_panel, in->hf_rows, in->hf_ld, in->hf_ret_num, in->hf_ret_den, in->hf_ret_rows);
+        rc = panel_in(b->hf_panel, b->fe_hf_prices, b->fe_hf_num, b->fe_hf_den, in->hf_panel, in->hf_rows, in->hf_ld,
+                      in->hf_ret_num, in->hf_ret_den, in->hf_ret_rows);
         if (rc != TP_OK) return rc;
         PUT(hf_start, in->hf_start, sizeof(int64_t) * (size_t)W);
         PUT(hf_row_idx, in->hf_row_idx, sizeof(int32_t) * (size_t)W * p.m);
@@ -507,13 +538,70 @@ int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in) {
 #undef PUT
     b->panel_ld = in->panel_ld;
     b->hf_ld = conj ? in->hf_ld : 0;
-    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
-    HIP_TRY(h, hipEventSynchronize(h->ev1));
-    float ms = 0;
-    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    h->h2d_ms = ms;
+    HIP_TRY(h, hipEventRecord(e1, st));
+    if (wait) {
+        HIP_TRY(h, hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
+        h->h2d_ms = ms;
+        // the price staging is needed only until the return panels exist
+        for (DevBuf* d : {&b->fe_prices, &b->fe_num, &b->fe_den, &b->fe_hf_prices, &b->fe_hf_num, &b->fe_hf_den}) release(*d);
+        b->upload_pending = false;
+    } else {
+        if (!b->upload_done) HIP_TRY(h, hipEventCreateWithFlags(&b->upload_done, hipEventDisableTiming));
+        HIP_TRY(h, hipEventRecord(b->upload_done, st));
+        b->upload_pending = true;
+        h->copy_timed = true;
+    }
     b->uploaded = true;
     return TP_OK;
+}
+
+int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in) {
+    if (!b) return TP_ERR_INVALID;
+    return upload_common(b, in, b->h->stream, true);
+}
+
+int tp_batch_upload_async(tp_batch_t b, const tp_inputs_t* in) {
+    if (!b) return TP_ERR_INVALID;
+    tp_handle_t h = b->h;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->copy_stream) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreate(&h->cp0));
+        HIP_TRY(h, hipEventCreate(&h->cp1));
+    }
+    return upload_common(b, in, h->copy_stream, false);
+}
+
+int tp_batch_upload_wait(tp_batch_t b) {
+    if (!b) return TP_ERR_INVALID;
+    tp_handle_t h = b->h;
+    if (!b->upload_done) return TP_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipEventSynchronize(b->upload_done));
+    if (h->copy_timed && hipEventQuery(h->cp1) == hipSuccess) {
+        float ms = 0;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->cp0, h->cp1));
+        h->h2d_ms = ms;
+        h->copy_timed = false;
+    }
+    return TP_OK;
+}
+
+// Page-locked host memory for panels and results: hipMemcpyAsync from / to it is a real DMA at PCIe rate and does
+// not block the calling thread (pageable buffers are staged through the runtime's own bounce buffers at about half
+// the rate).
+int tp_host_alloc(void** out, int64_t bytes) {
+    if (!out || bytes < 0) return TP_ERR_INVALID;
+    *out = nullptr;
+    if (hipHostMalloc(out, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocDefault) != hipSuccess) { *out = nullptr; return TP_ERR_HIP; }
+    return TP_OK;
+}
+
+int tp_host_free(void* p) {
+    if (!p) return TP_OK;
+    return hipHostFree(p) == hipSuccess ? TP_OK : TP_ERR_HIP;
 }
 
 int tp_batch_set_rhs(tp_batch_t b, const double* rhs) {
@@ -551,16 +639,22 @@ int tp_batch_download_rhs(tp_batch_t b, double* rhs_out) {
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const size_t bytes = sizeof(double) * (size_t)b->W * b->p.k;
-    const bool fresh = b->out_rhs.p == nullptr;
-    int rc = ensure(h, b->out_rhs, bytes);
-    if (rc != TP_OK) return rc;
-    if (fresh) {                      // the buffer did not exist during earlier runs: produce it now
-        rc = tp_batch_run(b);
-        if (rc != TP_OK) return rc;
-    }
+    if (!b->out_rhs.p || !b->rhs_valid)
+        return fail(h, TP_ERR_INVALID, "tp_batch_download_rhs: call tp_batch_keep_rhs before the tp_batch_run whose "
+                                       "right-hand sides are wanted");
     HIP_TRY(h, hipMemcpyAsync(rhs_out, b->out_rhs.p, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return harvest_kernel_time(h);
+}
+
+int tp_batch_keep_rhs(tp_batch_t b, int on) {
+    if (!b) return TP_ERR_INVALID;
+    tp_handle_t h = b->h;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));       // a running launch may still write the old buffer
+    b->rhs_valid = false;
+    if (!on) { release(b->out_rhs); return TP_OK; }
+    return ensure(h, b->out_rhs, sizeof(double) * (size_t)b->W * b->p.k);
 }
 
 int tp_batch_run(tp_batch_t b) {
@@ -568,6 +662,11 @@ int tp_batch_run(tp_batch_t b) {
     tp_handle_t h = b->h;
     if (!b->uploaded) return fail(h, TP_ERR_INVALID, "tp_batch_run before tp_batch_upload");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (b->upload_pending) {          // tp_batch_upload_async: the kernel stream waits for the copy stream's event
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, b->upload_done, 0));
+        b->upload_pending = false;
+    }
+    if (b->out_rhs.p) b->rhs_valid = true;
     if (b->pingpong) {
         b->parity ^= 1;
         if (b->gather_pending[b->parity]) {
@@ -581,6 +680,10 @@ int tp_batch_run(tp_batch_t b) {
     tp_kargs_t a = make_kargs(b);
     int rc = launch(b, a, b->W, true);
     if (rc != TP_OK) return rc;
+    if (b->upload_done) {             // asynchronous uploads in use: the next one must not overtake this launch
+        if (!b->ran) HIP_TRY(h, hipEventCreateWithFlags(&b->ran, hipEventDisableTiming));
+        HIP_TRY(h, hipEventRecord(b->ran, h->stream));
+    }
     return flush_gather(h);      // with the next kernel queued, put the requested gather of the previous run on its stream
 }
 
@@ -760,6 +863,77 @@ int tp_comm_init(tp_handle_t h, const void* id, int rank, int world) {
     return TP_OK;
 }
 
+int tp_comm_count(tp_handle_t h, int* ranks) {
+    if (!h || !ranks) return TP_ERR_INVALID;
+    *ranks = 0;
+    if (!h->comm) return fail(h, TP_ERR_INVALID, "tp_comm_count without a communicator");
+    NCCL_TRY(h, ncclCommCount(h->comm, ranks));
+    return TP_OK;
+}
+
+// Single-process form: one communicator over the n handles of this process (rank i = handles[i]), no id exchange
+// and no launcher - what main.py (one process, src/main.py:26) can use on an 8-GPU node.
+int tp_comm_init_all(tp_handle_t* handles, int n) {
+    if (!handles || n < 1) return TP_ERR_INVALID;
+    std::vector<int> devs((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (!handles[i]) return TP_ERR_INVALID;
+        if (handles[i]->comm) return fail(handles[i], TP_ERR_INVALID, "communicator already initialised");
+        devs[(size_t)i] = handles[i]->device;
+        for (int j = 0; j < i; ++j)
+            if (devs[(size_t)j] == devs[(size_t)i])
+                return fail(handles[0], TP_ERR_INVALID, "tp_comm_init_all: handles %d and %d share device %d (one rank per GPU)", j, i, devs[(size_t)i]);
+    }
+    std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    NCCL_TRY(handles[0], ncclCommInitAll(comms.data(), n, devs.data()));
+    for (int i = 0; i < n; ++i) { handles[i]->comm = comms[(size_t)i]; handles[i]->rank = i; handles[i]->world = n; }
+    return TP_OK;
+}
+
+// The gather of tp_batch_gather for the single-process communicator: batches[i] lives on rank i, all with the same
+// W; every rank's ncclGather pair is issued inside ONE group (a single thread drives all the devices), each on its
+// handle's kernel stream.  Waits for root's stream; the result stays in root's HBM and, with host buffers given,
+// is copied out [n x W x k] / [n x W].
+int tp_group_gather(tp_batch_t* batches, int n, int root, double* weights_all, int32_t* status_all) {
+    if (!batches || n < 1 || root < 0 || root >= n) return TP_ERR_INVALID;
+    for (int i = 0; i < n; ++i) {
+        if (!batches[i]) return TP_ERR_INVALID;
+        tp_handle_t h = batches[i]->h;
+        if (!h->comm || h->world != n || h->rank != i)
+            return fail(h, TP_ERR_INVALID, "tp_group_gather: batches[%d] is not on rank %d of an %d-rank communicator", i, i, n);
+        if (batches[i]->W != batches[0]->W || batches[i]->p.k != batches[0]->p.k)
+            return fail(h, TP_ERR_INVALID, "tp_group_gather: every rank must hold the same W and k");
+    }
+    tp_batch_t rb = batches[root];
+    tp_handle_t rh = rb->h;
+    const size_t nw = (size_t)rb->W * rb->p.k, ns = (size_t)rb->W;
+    HIP_TRY(rh, hipSetDevice(rh->device));
+    int rc = ensure(rh, rb->gather_w, sizeof(double) * nw * n);
+    if (rc == TP_OK) rc = ensure(rh, rb->gather_s, sizeof(int32_t) * ns * n);
+    if (rc != TP_OK) return rc;
+    NCCL_TRY(rh, ncclGroupStart());
+    for (int i = 0; i < n; ++i) {
+        tp_batch_t b = batches[i];
+        tp_handle_t h = b->h;
+        const bool is_root = i == root;
+        ncclResult_t r1 = ncclGather(b->out_weights(), is_root ? b->gather_w.p : nullptr, nw, ncclDouble, root, h->comm, h->stream);
+        ncclResult_t r2 = r1 == ncclSuccess
+            ? ncclGather(b->out_status(), is_root ? b->gather_s.p : nullptr, ns, ncclInt32, root, h->comm, h->stream) : r1;
+        if (r2 != ncclSuccess) { (void)ncclGroupEnd(); return fail(rh, TP_ERR_RCCL, "ncclGather (rank %d) failed: %s", i, ncclGetErrorString(r2)); }
+    }
+    NCCL_TRY(rh, ncclGroupEnd());
+    for (int i = 0; i < n; ++i) {
+        tp_handle_t h = batches[i]->h;
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        int rck = harvest_kernel_time(h);
+        if (rck != TP_OK) return rck;
+    }
+    rb->gathered = true;
+    if (weights_all || status_all) return tp_batch_download_gathered(rb, weights_all, status_all);
+    return TP_OK;
+}
+
 int tp_comm_destroy(tp_handle_t h) {
     if (!h) return TP_ERR_INVALID;
     if (h->deferred) { int rcf = flush_gather(h); if (rcf != TP_OK) return rcf; }
@@ -775,6 +949,10 @@ int tp_batch_gather(tp_batch_t b, int root, double* weights_all, int32_t* status
     if (!h->comm) return fail(h, TP_ERR_INVALID, "tp_batch_gather without tp_comm_init");
     if (root < 0 || root >= h->world) return fail(h, TP_ERR_INVALID, "bad root %d", root);
     HIP_TRY(h, hipSetDevice(h->device));
+    // collectives of one communicator must be issued in the same order on every rank: a gather still waiting to
+    // go onto the gather stream comes first, and this one only after it has finished there
+    if (h->deferred) { int rcf = flush_gather(h); if (rcf != TP_OK) return rcf; }
+    if (h->comm_stream) HIP_TRY(h, hipStreamSynchronize(h->comm_stream));
     const size_t nw = (size_t)b->W * b->p.k, ns = (size_t)b->W;
     const bool is_root = h->rank == root;
     if (is_root) {

@@ -30,18 +30,22 @@ import numpy as np
 import pandas as pd
 
 try:  # importable both as a package module and as a top-level `portfolio_calculations` (main.py style)
-    from . import _native, batch
+    from . import _native, batch, portfolio_specs, shard
 except ImportError:  # pragma: no cover - top-level import with the package directory on sys.path
     import _native  # type: ignore
     import batch  # type: ignore
+    import portfolio_specs  # type: ignore
+    import shard  # type: ignore
 
 logging_level = os.environ.get("LOGGING_LEVEL", logging.INFO)
 logging.basicConfig(level=logging_level)
 logger = logging.getLogger(__name__)
 
-# The reference's CHECK flag (ref:30) switches on O(n k^2) Python self-consistency loops; the
-# identities they test are covered by tests/ here, so the flag defaults to off and only enables the
-# cheap algebraic checks (ref:81-86, 420-428) on values returned by the device.
+# The reference's CHECK flag (ref:30): with it on, every helper re-derives its result a second way on the host and
+# raises the reference's ValueError when the two disagree (ref:81-86 w'Sw, ref:185-202 T against the sum of outer
+# products, ref:225-242 t against the sum of rows, ref:321-330 the intraday scatter against Y'Y, ref:420-428 the two
+# algebraic forms of c) - here the first way is the DEVICE's matrix, read back with tp_batch_download_matrix.  The
+# checks are O(n k^2) Python / numpy work per window, so the flag defaults to off (the reference ships it on).
 CHECK = False
 
 _CONJUGATE = ("conjugate_hf_vix_vw", "conjugate_hf_vix_ew", "conjugate_hf_epu_vw", "conjugate_hf_epu_ew")
@@ -128,6 +132,12 @@ def _daily_window_arrays(portfolio_spec, trading_date_ts, k_stock_prices_df, ris
     return np.ascontiguousarray(log_returns[keep]), np.ascontiguousarray(rf_rows[keep]), list(window.columns)
 
 
+def _host_excess_returns(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df):
+    """X (n_r x k) on the host, for the CHECK identities only (the device subtracts the risk-free rate itself)."""
+    log_returns, rf_rows, _ = _daily_window_arrays(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df)
+    return log_returns - rf_rows[:, None]
+
+
 def _intraday_window_returns(portfolio_spec, trading_date_ts, k_stock_intraday_prices_df):
     """Intraday log-returns of the last period (ref:299-314): bars in (date+1d-Delta, date+1d]."""
     span = _calendar_days_of(portfolio_spec["rolling_window_frequency"])
@@ -202,7 +212,12 @@ def calculate_portfolio_variance(portfolio_weights_df, covariance_matrix_df):
     w = portfolio_weights_df.sort_index()
     S = covariance_matrix_df.loc[w.index, w.index].to_numpy()
     v = w["Weight"].to_numpy()
-    return float(v @ (S @ v))
+    variance = float(v @ (S @ v))
+    if CHECK:  # ref:81-86: the label-aligned pandas product of the unsorted frames gives the same number
+        check = portfolio_weights_df["Weight"].T.dot(covariance_matrix_df.dot(portfolio_weights_df["Weight"]))
+        if not np.isclose(variance, check, atol=1e-4):
+            raise ValueError("Portfolio variance is not consistent.")
+    return variance
 
 
 # ======================================================================================================
@@ -280,6 +295,13 @@ def calculate_canonical_statistics_T(portfolio_spec, trading_date_ts, k_stock_pr
     win = _WindowOnDevice(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df, strategy="jeffreys")
     try:
         T, _ = win.matrix("gram")
+        if CHECK:  # ref:185-202: T against the sum of the rows' outer products
+            X = _host_excess_returns(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df)
+            T_check = np.zeros_like(T)
+            for xi in X:
+                T_check += np.outer(xi, xi)
+            if not np.isclose(T, T_check, rtol=1e-4, atol=1e-4).all():
+                raise ValueError("Canonical statistics T is not consistent.")
         return win.frame(T)
     finally:
         win.close()
@@ -290,6 +312,13 @@ def calculate_canonical_statistics_t(portfolio_spec, trading_date_ts, k_stock_pr
     win = _WindowOnDevice(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df, strategy="jeffreys")
     try:
         _, t = win.matrix("gram")
+        if CHECK:  # ref:225-242: t against the sum of the rows
+            X = _host_excess_returns(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df)
+            t_check = np.zeros_like(t)
+            for xi in X:
+                t_check += xi
+            if not np.isclose(t, t_check, rtol=1e-4, atol=1e-4).all():
+                raise ValueError("Canonical statistics t is not consistent.")
         return pd.DataFrame({0: t}, index=pd.Index(win.labels))
     finally:
         win.close()
@@ -311,6 +340,9 @@ def calculate_conjugate_prior_S(portfolio_spec, trading_date_ts, k_stock_intrada
         S0, _ = b.download_matrix(0, "prior")
     finally:
         b.close()
+    if CHECK:  # ref:321-330: cov(Y) * len(Y) against the uncentred Y'Y (rtol = atol = 1e-3, as in the reference)
+        if not np.isclose(S0 / conjugate_prior_n, Y.T @ Y, rtol=1e-3, atol=1e-3).all():
+            raise ValueError("Realized covariance matrix is not consistent.")
     return pd.DataFrame(S0, index=labels, columns=labels)
 
 
@@ -489,9 +521,11 @@ def _jorion_batch(kw, gamma, k, N):
     b = _native.Batch(dev, "jeffreys", k, N, kw["n_r"], 1.0, W, 0, flags=_native.FLAG_CENTER_BY_ROWS)
     try:
         b.upload(**{key: val for key, val in kw.items() if key not in ("n_r", "m")})
-        t = b.download_rhs()
+        b.keep_rhs()                                       # the first run also leaves t = X'1 (ref:222)
         x_t, status, _ = b.run().download(want_aux=False)
         _raise_on_status(status)
+        t = b.download_rhs()
+        b.keep_rhs(False)
         b.set_rhs(np.ones((W, k)))
         x_one, status, _ = b.run().download(want_aux=False)
         _raise_on_status(status)
@@ -580,9 +614,11 @@ def _greyserman_batch(kw, gamma, k, N, draws=None):
         try:
             b.set_shift(shift)
             b.upload(**sub)
-            t = b.download_rhs()
+            b.keep_rhs()                                   # the first run also leaves t = X'1 (ref:222)
             u_t, status, _ = b.run().download(want_aux=False)
             _raise_on_status(status)
+            t = b.download_rhs()
+            b.keep_rhs(False)
             b.set_rhs(np.ones((Wb, k)))
             u_one, status, _ = b.run().download(want_aux=False)
             _raise_on_status(status)
@@ -694,6 +730,38 @@ def _pack_window(trading_date_ts, portfolio_spec, market_data):
     return item
 
 
+# windows below which one GPU is used even when several are visible (a launch per device has a fixed cost)
+SHARD_MIN_WINDOWS = int(os.environ.get("TP_SHARD_MIN_WINDOWS", "2048"))
+
+
+def _device_posterior_batch(strategy, k, N, gamma, kw):
+    """The batched device call behind every estimator: on a node with several visible GPUs and enough windows, the
+    windows shard over ALL of them inside this one process (`shard.run_sharded`: contiguous shards, one grouped RCCL
+    gather to device 0; the reference's driver is a single process, src/main.py:26); otherwise one device."""
+    n_windows = len(kw["n_rows"]) if kw.get("n_rows") is not None else len(kw["start"])
+    if n_windows >= SHARD_MIN_WINDOWS and _native.device_count() > 1:
+        return shard.run_sharded(_native.default_group(), strategy, k, N, gamma, kw, want_aux=True)
+    return _native.posterior_batch(strategy, k, N, gamma, **kw)
+
+
+def _dates_key(trading_dates):
+    return tuple(pd.Timestamp(ts).value for ts in trading_dates)
+
+
+def _spec_cache_key(portfolio_spec):
+    return tuple(portfolio_spec.get(name) for name in ("weighting_strategy", "size", "risk_aversion", "rebalancing_frequency",
+                                                        "rolling_window", "rolling_window_frequency", "mcm_scaling"))
+
+
+def _cache_slot(portfolio_spec, trading_dates, market_data):
+    """(cache dict, key, MCM frame) of a conjugate spec's weights.  The cache lives on the panels object, so it dies
+    with the price / caps / intraday / risk-free frames it was computed from; the VIX / EPU frame is part of the key
+    and is kept alive by the entry (its `id` cannot be recycled while the entry exists)."""
+    frame = market_data["vix_prices_df" if "_vix_" in portfolio_spec["weighting_strategy"] else "epu_prices_df"]
+    cache = batch.panels_for(market_data, portfolio_spec["rolling_window_frequency"]).weights_cache
+    return cache, (_spec_cache_key(portfolio_spec), _dates_key(trading_dates), id(frame)), frame
+
+
 def _weights_for_dates(trading_dates, portfolio_spec, market_data):
     """(weights [W x k], labels, column indices [W x k], market caps [W x k]) for MANY rebalancing dates: one
     host pass (`batch.pack_windows`) and, for the estimators, one device batch."""
@@ -704,24 +772,99 @@ def _weights_for_dates(trading_dates, portfolio_spec, market_data):
         logger.error("Unknown weights spec.")
         raise ValueError("Unknown weights spec.")
     members_of = _members_provider(market_data)
+    k, N, gamma = portfolio_spec["size"], portfolio_spec["rolling_window"], portfolio_spec.get("risk_aversion")
+    if strategy in ("vw", "ew"):
+        # passive strategies: universe selection only (ref:990-997 reads neither returns nor the risk-free rate)
+        cols, labels, caps = batch.pack_universes(list(trading_dates), portfolio_spec, market_data, members_of=members_of)
+        if strategy == "vw":
+            weights = caps / caps.sum(axis=1, keepdims=True)             # ref:692-695 (already cap-descending)
+        else:
+            weights = np.full(caps.shape, 1 / k)                         # ref:670-672
+        return weights, labels, cols, caps
+    if strategy in _CONJUGATE:
+        cache, key, frame = _cache_slot(portfolio_spec, trading_dates, market_data)
+        hit = cache.get(key)
+        if hit is not None and hit[1] is frame:                          # filled by a cross-spec batch
+            return hit[0]
     kw, labels, caps = batch.pack_windows(list(trading_dates), portfolio_spec, market_data, members_of=members_of,
                                           return_caps=True)
     cols = kw["col_idx"]
-    k, N, gamma = portfolio_spec["size"], portfolio_spec["rolling_window"], portfolio_spec.get("risk_aversion")
-    if strategy == "vw":
-        weights = caps / caps.sum(axis=1, keepdims=True)                 # ref:692-695 (already cap-descending)
-    elif strategy == "ew":
-        weights = np.full(caps.shape, 1 / k)                             # ref:670-672
-    elif strategy == "jorion":
+    if strategy == "jorion":
         kw.pop("start", None)
         weights = _jorion_batch(kw, gamma, k, N)
     elif strategy == "greyserman":
         weights = _greyserman_batch(kw, gamma, k, N)
     else:
         conj = strategy in _CONJUGATE
-        weights, status, aux = _native.posterior_batch("conjugate" if conj else "jeffreys", k, N, gamma, **kw)
+        weights, status, aux = _device_posterior_batch("conjugate" if conj else "jeffreys", k, N, gamma, kw)
         _raise_on_status(status)
     return weights, labels, cols, caps
+
+
+def _batch_family(portfolio_spec):
+    """Conjugate specs with equal (size, window, frequencies) see the same windows: only w0 / n0 / gamma differ."""
+    return tuple(portfolio_spec.get(name) for name in ("size", "rebalancing_frequency", "rolling_window", "rolling_window_frequency"))
+
+
+def calculate_weights_for_specs(trading_dates, portfolio_specs_list, market_data):
+    """Weights of SEVERAL conjugate specs of one grid for the same dates with ONE host pack, ONE upload of the
+    panels and ONE device batch of len(specs) x len(dates) windows ("vectorised over days
+    and over specs"): the specs share the windows (rows, columns, risk-free adjustment, intraday rows) and differ in
+    the prior only - w0 (vw / ew, ref:361-380), n0 (VIX / EPU, mcm_scaling, ref:247-267) and gamma.  Returns one
+    (weights, labels, cols, caps) per spec, bit-identical to `_weights_for_dates` spec by spec (windows are
+    independent), and remembers them for the `backtest_portfolio` calls that follow."""
+    specs = list(portfolio_specs_list)
+    if not specs:
+        return []
+    if any(sp["weighting_strategy"] not in _CONJUGATE for sp in specs) or len({_batch_family(sp) for sp in specs}) != 1:
+        raise ValueError("calculate_weights_for_specs: conjugate specs of equal size, window and frequencies expected")
+    trading_dates = list(trading_dates)
+    members_of = _members_provider(market_data)
+    first = specs[0]
+    kw, labels, caps = batch.pack_windows(trading_dates, first, market_data, members_of=members_of, return_caps=True)
+    n_dates, n_specs = len(trading_dates), len(specs)
+    k, N = first["size"], first["rolling_window"]
+    gammas = [sp["risk_aversion"] for sp in specs]
+    same_gamma = all(g == gammas[0] for g in gammas)
+    per_window = ("row_idx", "n_rows", "col_idx", "rf_adj", "hf_row_idx", "hf_count")
+    big = {key: (np.concatenate([val] * n_specs, axis=0) if key in per_window and val is not None else val)
+           for key, val in kw.items()}
+    priors = [(kw["w0"], kw["n0"])] + [batch.prior_inputs(trading_dates, sp, market_data, caps) for sp in specs[1:]]
+    big["w0"] = np.concatenate([p[0] for p in priors], axis=0)
+    big["n0"] = np.concatenate([p[1] for p in priors], axis=0)
+    # 1/gamma is the last factor of ref:836: with different risk aversions in one batch the device runs with
+    # gamma = 1 and the same multiplication happens here (same rounding: (1/gamma) * x in both places)
+    weights, status, _ = _device_posterior_batch("conjugate", k, N, gammas[0] if same_gamma else 1.0, big)
+    _raise_on_status(status)
+    out = []
+    for i, sp in enumerate(specs):
+        w = weights[i * n_dates:(i + 1) * n_dates]
+        if not same_gamma:
+            w = 1.0 / sp["risk_aversion"] * w
+        res = (w, labels, kw["col_idx"], caps)
+        cache, key, frame = _cache_slot(sp, trading_dates, market_data)
+        if len(cache) > 64:
+            cache.clear()
+        cache[key] = (res, frame)
+        out.append(res)
+    return out
+
+
+def _prefetch_siblings(portfolio_spec, rebalance_dates, market_data):
+    """`backtest_portfolio` is called once per spec (src/main.py:48): when the spec is a conjugate spec of the grid
+    `portfolio_specs.create_portfolio_specs()` returned last, solve all its conjugate siblings with the same
+    windows in the same device batch, so that their own `backtest_portfolio` calls find the weights ready."""
+    if portfolio_spec["weighting_strategy"] not in _CONJUGATE:
+        return
+    cache, key, frame = _cache_slot(portfolio_spec, rebalance_dates, market_data)
+    if key in cache and cache[key][1] is frame:
+        return
+    family = _batch_family(portfolio_spec)
+    siblings = [sp for sp in portfolio_specs.last_grid().values()
+                if sp["weighting_strategy"] in _CONJUGATE and _batch_family(sp) == family
+                and _spec_cache_key(sp) != _spec_cache_key(portfolio_spec)]
+    if siblings:
+        calculate_weights_for_specs(rebalance_dates, [portfolio_spec] + siblings, market_data)
 
 
 def calculate_portfolio_weights_batch(trading_dates, portfolio_spec, market_data):
@@ -965,6 +1108,30 @@ def backtest_portfolio(portfolio_spec, ts_start_date, ts_end_date, market_data):
     trading_dates = [pd.Timestamp(ts) for ts in market_data["stock_prices_df"].index]
     trading_dates = [ts for ts in trading_dates if ts_start_date <= ts <= ts_end_date]
     rebalance_dates = rebalancing_schedule(trading_dates, portfolio_spec["rebalancing_frequency"])
+    _prefetch_siblings(portfolio_spec, rebalance_dates, market_data)
     weights, labels, cols, caps = _weights_for_dates(rebalance_dates, portfolio_spec, market_data)
     tickers = batch.panels_for(market_data, portfolio_spec["rolling_window_frequency"]).tickers
     return _replay_backtest(trading_dates, rebalance_dates, weights, cols, caps, tickers, portfolio_spec, market_data)
+
+
+def backtest_portfolios(portfolio_specs_dict, ts_start_date, ts_end_date, market_data):
+    """`backtest_portfolio` for a whole spec grid ({name: spec}, as `create_portfolio_specs` returns it): the
+    conjugate specs that share their windows go to the device in ONE batch (`calculate_weights_for_specs`), then
+    every spec is replayed.  Specs outside the scope of this build (shrinkage, Black-Litterman: pypfopt) are
+    skipped with a warning - the reference's own loop (src/main.py:48) would stop at the first of them."""
+    trading_dates = [pd.Timestamp(ts) for ts in market_data["stock_prices_df"].index]
+    trading_dates = [ts for ts in trading_dates if ts_start_date <= ts <= ts_end_date]
+    groups = {}
+    for name, sp in portfolio_specs_dict.items():
+        if sp["weighting_strategy"] in _CONJUGATE:
+            groups.setdefault(_batch_family(sp), []).append(sp)
+    for family, specs in groups.items():
+        if len(specs) > 1:
+            calculate_weights_for_specs(rebalancing_schedule(trading_dates, specs[0]["rebalancing_frequency"]), specs, market_data)
+    out = {}
+    for name, sp in portfolio_specs_dict.items():
+        if sp["weighting_strategy"] in _OUT_OF_SCOPE:
+            logger.warning(f"{name}: {sp['weighting_strategy']} is outside the scope of this build (pypfopt); skipped.")
+            continue
+        out[name] = backtest_portfolio(sp, ts_start_date, ts_end_date, market_data)
+    return out

@@ -84,6 +84,16 @@ def spec_key(weighting_strategy, size, risk_aversion, turnover_cost, rebalancing
             f"_mcm_scaling_{na(mcm_scaling)}")
 
 
+_LAST_GRID = {}
+
+
+def last_grid():
+    """The spec dict most recently returned by `create_portfolio_specs` ({} before the first call).
+    `portfolio_calculations.backtest_portfolio` looks here for the conjugate siblings of the spec it is given, so
+    that the reference's spec loop (src/main.py:48) costs ONE packed upload and ONE device batch for all of them."""
+    return _LAST_GRID
+
+
 def create_portfolio_specs(grid=None):
     """Cartesian product of the grid; passive strategies have no risk aversion, only the conjugate
     strategies have an MCM scaling (ref portfolio_specs.py:66-70)."""
@@ -109,4 +119,6 @@ def create_portfolio_specs(grid=None):
                 "mcm_scaling": scaling,
                 "display_name": get_display_name_from_full_name(key),
             }
+    global _LAST_GRID
+    _LAST_GRID = specs
     return specs

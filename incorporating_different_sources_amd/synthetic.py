@@ -38,10 +38,12 @@ def config_shapes(config_id: int) -> dict:
 
 
 def make_kernel_inputs(k: int, N: int, W: int, seed: int, hf_days: int = 1, gamma: float = 5.0,
-                       mcm_scaling: float = 1.0, prior: str = "vw") -> dict:
+                       mcm_scaling: float = 1.0, prior: str = "vw", hf_period: int = 0) -> dict:
     """Rolling windows `start_w = w` over a shared daily panel of `D = W + n_r` rows, and
     `hf_start_w = w * 78` over a shared intraday-return panel of `(W + hf_days - 1) * 78` rows
-    (window w uses the `m = hf_days*78 - 1` returns that start there)."""
+    (window w uses the `m = hf_days*78 - 1` returns that start there).  `hf_period > 0`: the intraday panel
+    holds only that many days and window w starts at day `w % hf_period` (multi-day intraday windows at
+    BASELINE's largest window counts would otherwise need hundreds of GB of host memory)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     n_r = N - 1
     m = hf_days * BARS_PER_DAY - 1
@@ -49,7 +51,8 @@ def make_kernel_inputs(k: int, N: int, W: int, seed: int, hf_days: int = 1, gamm
     beta = rng.uniform(0.5, 1.5, size=k)
     f = rng.normal(0.0, 0.01, size=D)
     panel = 3e-4 + f[:, None] * beta[None, :] + rng.normal(0.0, 0.01, size=(D, k))
-    H = (W + hf_days - 1) * BARS_PER_DAY
+    hf_day_count = min(W, hf_period) if hf_period > 0 else W
+    H = (hf_day_count + hf_days - 1) * BARS_PER_DAY
     hf_panel = rng.normal(0.0, 0.001, size=(H, k))
     if prior == "vw":
         caps = rng.uniform(1e9, 1e11, size=(W, k))
@@ -68,7 +71,7 @@ def make_kernel_inputs(k: int, N: int, W: int, seed: int, hf_days: int = 1, gamm
     return dict(k=k, N=N, n_r=n_r, m=m, W=W, gamma=gamma, seed=seed,
                 panel=np.ascontiguousarray(panel), start=np.arange(W, dtype=np.int64),
                 hf_panel=np.ascontiguousarray(hf_panel),
-                hf_start=np.arange(W, dtype=np.int64) * BARS_PER_DAY,
+                hf_start=(np.arange(W, dtype=np.int64) % hf_day_count) * BARS_PER_DAY,
                 w0=np.ascontiguousarray(w0), n0=np.ascontiguousarray(n0))
 
 

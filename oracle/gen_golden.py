@@ -167,7 +167,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     holder = {"tickers": []}
     pc, ps = import_reference(holder)
-    which = sys.argv[1:] or ["single", "backtest", "specs", "large", "jorion", "greyserman"]
+    which = sys.argv[1:] or ["single", "backtest", "specs", "large", "jorion", "greyserman", "shipped"]
     conj = ["conjugate_hf_vix_vw", "conjugate_hf_vix_ew"]
     if "single" in which:
         # BASELINE config 1 shapes (k=10, N=60), 4 windows, all intermediates + inputs stored
@@ -238,6 +238,18 @@ def main():
         print("wrote greyserman_single.npz")
         gen_backtest(pc, holder, "backtest_k10_n60_daily_greyserman", ["greyserman"], 10, 60, "daily", "daily", 85, 14,
                      20240001, 65, np_seed=20240077)
+    if "shipped" in which:
+        # The configuration the reference actually ships (ref portfolio_specs.py:52-62): size 50, 250-WEEKLY window,
+        # monthly rebalancing, gamma 5, 15 bp, mcm_scaling 1 - the seven strategies of its grid that are in scope
+        # (shrinkage and Black-Litterman need pypfopt, which is not in this image), in main.py's order, on a
+        # synthetic market of 60 tickers x 1,424 business days (250 complete weekly bins before the first date),
+        # with NaN risk-free days.  Greyserman draws from numpy's global generator: seeded.
+        shipped = [s for s in ps.create_portfolio_specs().values()
+                   if s["weighting_strategy"] not in ("shrinkage", "black_litterman")]
+        assert all(s["size"] == 50 and s["rolling_window"] == 250 and s["rolling_window_frequency"] == "weekly"
+                   and s["rebalancing_frequency"] == "monthly" for s in shipped)
+        gen_backtest(pc, holder, "backtest_shipped_k50_n250_weekly_monthly", [s["weighting_strategy"] for s in shipped],
+                     50, 250, "weekly", "monthly", 1424, 60, 20240050, 1262, rf_nan_every=23, np_seed=20240051)
     if "specs" in which:
         specs = ps.create_portfolio_specs()
         keys = list(specs.keys())

@@ -1,4 +1,5 @@
-"""N > 1 host path on CPU: world_size-2 gloo job (two processes), sharded windows == unsharded."""
+"""N > 1 host path on CPU: world_size-2 jobs (two processes), sharded windows == unsharded; the package's TCP
+control plane and a gloo transport injected by the test; the single-process device group with stand-in devices."""
 import json
 import os
 import socket
@@ -6,6 +7,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from conftest import REPO
 from incorporating_different_sources_amd import shard
@@ -33,23 +35,126 @@ def test_slice_window_inputs_rebases_offsets():
         a = inp["hf_panel"][inp["hf_start"][w]: inp["hf_start"][w] + inp["m"]]
         b = s["hf_panel"][s["hf_start"][i]: s["hf_start"][i] + inp["m"]]
         assert np.array_equal(a, b)
-    assert s["panel"].shape[0] == 4 + inp["n_r"] + 0 + 1 - 1 + 0 or s["panel"].shape[0] == (8 - 4) + inp["n_r"]
+    assert s["panel"].shape[0] == (8 - 4) + inp["n_r"]
 
 
-def test_world_size_2_gloo_sharded_equals_unsharded(tmp_path):
+def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    out = tmp_path / "result.json"
+        return s.getsockname()[1]
+
+
+def _run_world(tmp_path, transport, world=2, extra_env=None):
+    out = tmp_path / f"result_{transport}.json"
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "_shard_worker.py"), str(out)],
+    port = _free_port()
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", TMPDIR=str(tmp_path))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "_shard_worker.py"), str(out), transport],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         o, _ = p.communicate(timeout=300)
         assert p.returncode == 0, o.decode()[-2000:]
-    res = json.load(open(out))
-    assert res["world"] == 2 and res["shape"] == [37, 12] and res["uid_ok"] and res["tmax"] == 2.0
+    return json.load(open(out))
+
+
+def test_world_size_2_gloo_sharded_equals_unsharded(tmp_path):
+    res = _run_world(tmp_path, "gloo")
+    assert res["world"] == 2 and res["shape"] == [37, 12] and res["uid_ok"] and res["tmax"] == 2.0 and res["tsum"] == 3.0
     assert res["max_abs_diff"] == 0.0      # windows are independent: sharding changes nothing, bit for bit
+
+
+@pytest.mark.parametrize("explicit_port", [False, True])
+def test_world_size_2_tcp_control_plane(tmp_path, explicit_port):
+    """The package's own rendezvous: a file in the temp directory (torchrun owns MASTER_PORT) or TP_CONTROL_PORT."""
+    extra = {"TP_CONTROL_PORT": str(_free_port())} if explicit_port else {}
+    res = _run_world(tmp_path, "tcp", extra_env=extra)
+    assert res["world"] == 2 and res["shape"] == [37, 12] and res["uid_ok"] and res["tmax"] == 2.0 and res["tsum"] == 3.0
+    assert res["max_abs_diff"] == 0.0
+
+
+def test_world_size_3_tcp_control_plane(tmp_path):
+    res = _run_world(tmp_path, "tcp", world=3)
+    assert res["world"] == 3 and res["tmax"] == 3.0 and res["tsum"] == 6.0 and res["max_abs_diff"] == 0.0
+
+
+def test_package_does_not_import_torch():
+    """north_star: no PyTorch in the product - not even as the launcher's rendezvous."""
+    pkg = os.path.join(REPO, "incorporating_different_sources_amd")
+    for name in os.listdir(pkg):
+        if name.endswith(".py"):
+            src = open(os.path.join(pkg, name)).read()
+            assert "import torch" not in src and "from torch" not in src, name
+    code = ("import sys; sys.path.insert(0, %r); import incorporating_different_sources_amd.shard, "
+            "incorporating_different_sources_amd.portfolio_calculations; assert 'torch' not in sys.modules" % REPO)
+    subprocess.check_call([sys.executable, "-c", code])
+
+
+# ---- single process, several devices: `run_sharded` with stand-in devices whose batches compute with the oracle
+class _FakeBatch:
+    def __init__(self, dev, strategy, k, N, n_r, gamma, W, m, flags):
+        self.dev, self.args, self.W, self.k = dev, (strategy, k, N, gamma, n_r, m, flags), W, k
+        self.rhs = self.shift = None
+
+    def set_rhs(self, rhs):
+        self.rhs = rhs
+
+    def set_shift(self, shift):
+        self.shift = shift
+
+    def upload(self, **kw):
+        self.kw = kw
+        return self
+
+    def run(self):
+        from oracle import oracle
+        strategy, k, N, gamma, n_r, m, flags = self.args
+        kw = {key: val for key, val in self.kw.items() if val is not None}
+        self.out = oracle.posterior_batch(strategy, k, N, gamma, n_r=n_r, m=m, **kw)
+        self.dev.launches.append(self.W)
+        return self
+
+    def download(self, want_aux=True):
+        return self.out
+
+    def close(self):
+        self.dev.closed += 1
+
+
+class _FakeDevice:
+    def __init__(self):
+        self.launches, self.closed = [], 0
+
+    def batch(self, strategy, k, N, n_r, gamma, W, m=0, flags=0):
+        return _FakeBatch(self, strategy, k, N, n_r, gamma, W, m, flags)
+
+
+class _FakeGroup:
+    def __init__(self, n):
+        self.devices = [_FakeDevice() for _ in range(n)]
+        self.world = n
+        self.gathers = 0
+
+    def gather(self, batches, root=0):
+        self.gathers += 1
+        assert len({b.W for b in batches}) == 1          # RCCL's gather wants equal counts
+        return np.stack([b.out[0] for b in batches]), np.stack([b.out[1] for b in batches])
+
+
+@pytest.mark.parametrize("world,W", [(2, 37), (3, 10), (4, 3), (8, 64)])
+def test_run_sharded_equals_unsharded_bitwise(world, W):
+    from incorporating_different_sources_amd import synthetic
+    from oracle import oracle
+    k, N = 9, 24
+    inp = synthetic.make_kernel_inputs(k, N, W, seed=77)
+    kw = dict(panel=inp["panel"], start=inp["start"], n_r=inp["n_r"], hf_panel=inp["hf_panel"],
+              hf_start=inp["hf_start"], m=inp["m"], w0=inp["w0"], n0=inp["n0"])
+    ref_w, ref_s, ref_aux = oracle.posterior_batch("conjugate", k, N, 5.0, **kw)
+    group = _FakeGroup(world)
+    w, s, aux = shard.run_sharded(group, "conjugate", k, N, 5.0, kw, want_aux=True)
+    assert np.array_equal(w, ref_w) and np.array_equal(s, ref_s) and np.array_equal(aux, ref_aux)
+    assert group.gathers == 1                                        # ONE gather, no other collective
+    assert all(len(d.launches) == 1 and d.closed == 1 for d in group.devices)
+    assert len({d.launches[0] for d in group.devices}) == 1          # equal (padded) shard sizes
