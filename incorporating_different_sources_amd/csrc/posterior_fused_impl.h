@@ -331,6 +331,9 @@ __device__ __forceinline__ void store_chunk(double* __restrict__ buf, const doub
     constexpr int kI = C::NT - 1;            // the border column k always lies in the last 16-column group
     const int kc = k - 16 * kI;
     const bool cvl = cb < kc;                // column validity in the last group
+    // intraday rows, one-pass scatter: column k+1 (when the last group has a spare column) carries ones, so that
+    // the MFMAs also produce the column sums of the shifted rows (phase C)
+    const double hfone = (HF && kc < 15 && cb == kc + 1) ? 1.0 : 0.0;
 #pragma unroll
     for (int ps = 0; ps < C::PASSES; ++ps) {
         const int rl = ps * C::ROWS_PER_PASS + (tid >> 4);
@@ -339,8 +342,8 @@ __device__ __forceinline__ void store_chunk(double* __restrict__ buf, const doub
 #pragma unroll
             for (int i = 0; i < C::NT; ++i) {
                 const int c = cb + 16 * i;
-                v[ps][i] -= lds[C::OFF_YBAR + c];                            // ybar, w0 are zero-padded
-                if (i == kI) v[ps][i] = cvl ? v[ps][i] : 0.0;
+                v[ps][i] -= lds[C::OFF_YBAR + c];                            // ybar / shift row, w0 are zero-padded
+                if (i == kI) v[ps][i] = cvl ? v[ps][i] : hfone;
             }
             if (!full) {
                 const bool rv = chunk * C::CH + rl < count;
@@ -410,7 +413,9 @@ __device__ __forceinline__ void gram_phase_lean(const RowSource& src, int k, dou
     const unsigned dlast = 8u * (unsigned)((cl < k ? cl : k - 1) - cb);            // k >= 16 (NT-1): only the last group clamps
     const unsigned wlds = (unsigned)((tid >> 4) * C::LDX + cb);
     const bool cvl = cb < kc;
-    const double border = (!HF && cb == kc) ? 1.0 : 0.0;
+    // daily rows: ones in the border column (t = X'1); intraday rows: ones in the spare column k+1 (column sums
+    // of the shifted rows for the one-pass scatter, phase C) when the last column group has one
+    const double border = (!HF && cb == kc) ? 1.0 : ((HF && kc < 15 && cb == kc + 1) ? 1.0 : 0.0);
     double v[C::PASSES][C::NT];
     double sub[C::PASSES];
     int row = tid >> 4;                       // this lane's row in the next chunk to be loaded (pass 0)
@@ -434,8 +439,8 @@ __device__ __forceinline__ void gram_phase_lean(const RowSource& src, int k, dou
         for (int ps = 0; ps < C::PASSES; ++ps) {
             if (HF) {
 #pragma unroll
-                for (int i = 0; i < C::NT; ++i) v[ps][i] -= lds[C::OFF_YBAR + cb + 16 * i];    // ybar, w0 are zero-padded
-                v[ps][kI] = cvl ? v[ps][kI] : 0.0;
+                for (int i = 0; i < C::NT; ++i) v[ps][i] -= lds[C::OFF_YBAR + cb + 16 * i];    // ybar / shift row, w0: zero-padded
+                v[ps][kI] = cvl ? v[ps][kI] : border;
             } else {
                 if (has_sub) {
 #pragma unroll
@@ -611,10 +616,31 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
         hs.count = A.hf_count ? A.hf_count[w] : A.m;
         hs.off32 = (A.hf_off32 & (hs.ridx ? 1 : 2)) != 0;
         TP_MARK(0);
-        // ---- phase A: column means (ref:317, DataFrame.cov centres first) and w0 into LDS.
-        // Same thread geometry as the staging (16 threads per row, 16-lane coalesced segments): every
-        // thread sums its rows, the ROWS_PER_PASS partial rows meet in LDS and are added in row order.
-        {
+        // ---- phase A.  The centred scatter of ref:317 (DataFrame.cov centres first) WITHOUT a pass of its own over
+        // the intraday rows: with the rows shifted by the window's first row s (the shifted-data form of the
+        // covariance: exact for constant columns, and |ybar - s| is of the order of one standard deviation, so the
+        // correction below cancels about one bit),
+        //     sum (y - ybar)(y - ybar)' = sum (y - s)(y - s)' - (1/m) t t',   t = sum (y - s),
+        // and t comes out of the SAME MFMAs through a column of ones in the spare column k+1 (phase C applies the
+        // rank-one term).  The means pass cost two HBM round trips per window (7 % of its lifetime) and made the
+        // intraday panel - the one input that really streams from HBM - be read twice.  Universe sizes with
+        // k+1 a multiple of 16 have no spare column and keep the two-pass form.
+        const bool shifted = kc < 15;
+        if (shifted) {
+            TP_LANE_CONSTANTS();
+            const long long row0 = hs.ridx ? (long long)hs.ridx[0] : hs.first;
+            const double* p0 = hs.base + row0 * (long long)hs.ld;
+            for (int c = tid; c < C::KP; c += C::NTHREADS) {
+                const int cl = c < k ? c : k - 1;
+                const double sv = p0[cols ? cols[cl] : cl];
+                lds[C::OFF_YBAR + c] = (c < k) ? sv : 0.0;
+                lds[C::OFF_W0 + c] = (c < k) ? A.w0[w * k + cl] : 0.0;
+            }
+            __syncthreads();
+        } else {
+            // column means in a pass of their own.  Same thread geometry as the staging (16 threads per row, 16-lane
+            // coalesced segments): every thread sums its rows, the ROWS_PER_PASS partial rows meet in LDS and are
+            // added in row order.
             TP_LANE_CONSTANTS();
             double cs[C::NT];
 #pragma unroll
@@ -666,7 +692,36 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
         if constexpr (LEAN) gram_phase_lean<C, true, FIX>(hs, k, lds, tid0, wv, acc);
         else gram_phase<C, true, FIX>(hs, cols, k, lds, tid0, wv, acc, nullptr);
         TP_MARK(2);
-        // ---- phase C: q0, c, scaling (ref:333, 415-418)
+        // ---- phase C: (one-pass form) the rank-one term of the centring; q0, c, scaling (ref:333, 415-418)
+        if (shifted) {
+            TP_LANE_CONSTANTS();
+            // column k+1 holds t_i = sum_r (y_r - s)_i for the asset columns and sum_r u_r in row k (u = (y - s).w0)
+            wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
+                for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
+                    constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
+                    if constexpr (J == kI) {
+                        if (fr == kc + 1) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                lds[C::OFF_YVEC + 16 * I + fq + 4 * r] = (I < kI || fq + 4 * r <= kc) ? acc[s][r] : 0.0;
+                        }
+                    }
+                });
+            });
+            __syncthreads();
+            const double invm = 1.0 / (double)hs.count;
+            wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
+                for_tiles<C, decltype(wc)::value>([&](auto sc_, auto Ic, auto Jc) __attribute__((always_inline)) {
+                    constexpr int s = decltype(sc_)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
+                    const double tj = lds[C::OFF_YVEC + 16 * J + fr];          // zero beyond column k
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double ti = lds[C::OFF_YVEC + 16 * I + fq + 4 * r];
+                        acc[s][r] = fma(-(ti * invm), tj, acc[s][r]);
+                    }
+                });
+            });
+        }
         {
         TP_LANE_CONSTANTS();
         const double mm = (double)hs.count;

@@ -44,16 +44,16 @@ def test_backtest_portfolio_matches_reference(pc, name):
         assert np.array_equal(r.index.values.astype("datetime64[ns]").astype(np.int64), g[f"{strat}_returns_dates"])
         assert np.array_equal(t.index.values.astype("datetime64[ns]").astype(np.int64), g[f"{strat}_turnover_dates"])
         assert np.array_equal(mdf.index.values.astype("datetime64[ns]").astype(np.int64), g[f"{strat}_metrics_dates"])
-        np.testing.assert_allclose(r.to_numpy(), g[f"{strat}_returns"], rtol=1e-8, atol=1e-11, err_msg=strat)
-        np.testing.assert_allclose(t.to_numpy(), g[f"{strat}_turnover"], rtol=1e-8, atol=1e-11, err_msg=strat)
-        np.testing.assert_allclose(mdf.to_numpy(), g[f"{strat}_metrics"], rtol=1e-8, atol=1e-11, equal_nan=True,
+        np.testing.assert_allclose(r.to_numpy(), g[f"{strat}_returns"], rtol=1e-10, atol=1e-13, err_msg=strat)
+        np.testing.assert_allclose(t.to_numpy(), g[f"{strat}_turnover"], rtol=1e-10, atol=1e-13, err_msg=strat)
+        np.testing.assert_allclose(mdf.to_numpy(), g[f"{strat}_metrics"], rtol=1e-10, atol=1e-13, equal_nan=True,
                                    err_msg=strat)
         # per-date weights through the dispatch function, label order included (ref:1097 needs it)
         for i, d in enumerate(mdf.index[:: max(1, len(mdf) // 7)]):
             j = list(mdf.index).index(d)
             w = pc.calculate_portfolio_weights(d, spec, md)
             assert [tickers.index(s) for s in w.index] == list(g[f"{strat}_weights_tickers"][j])
-            np.testing.assert_allclose(w["Weight"].to_numpy(), g[f"{strat}_weights"][j], rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(w["Weight"].to_numpy(), g[f"{strat}_weights"][j], rtol=0, atol=1e-10)
 
 
 @pytest.mark.parametrize("name", ["single_k10_n60", "single_k33_n80"])
@@ -77,11 +77,11 @@ def test_helper_functions_match_reference(pc, name):
             c = pc.calculate_conjugate_c(spec, date, prices_df, caps_df, intraday_df, mcm_df)
             assert c == pytest.approx(float(g[f"{tag}_c"]), rel=1e-12)
             w1 = pc.calculate_conjugate_posterior_w(spec, date, prices_df, caps_df, intraday_df, mcm_df, rf_df)
-            np.testing.assert_allclose(w1.loc[order, "Weight"].to_numpy(), g[f"{tag}_w1"], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(w1.loc[order, "Weight"].to_numpy(), g[f"{tag}_w1"], rtol=0, atol=1e-10)
             nu = pc.calculate_mean_conjugate_posterior_nu(spec, date, prices_df, caps_df, intraday_df, mcm_df, rf_df)
-            np.testing.assert_allclose(nu.loc[order, "Weight"].to_numpy(), g[f"{tag}_nu"], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(nu.loc[order, "Weight"].to_numpy(), g[f"{tag}_nu"], rtol=0, atol=1e-10)
             wts = pc.calculate_conjugate_hf_mcm_portfolio(spec, date, caps_df, prices_df, intraday_df, mcm_df, rf_df)
-            np.testing.assert_allclose(wts.loc[order, "Weight"].to_numpy(), g[f"{tag}_weights"], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(wts.loc[order, "Weight"].to_numpy(), g[f"{tag}_weights"], rtol=0, atol=1e-10)
         spec = _spec("jeffreys", k, N, "daily", "daily")
         tag = f"w{w}_jeffreys"
         T = pc.calculate_canonical_statistics_T(spec, date, prices_df, rf_df)
@@ -89,7 +89,7 @@ def test_helper_functions_match_reference(pc, name):
         t = pc.calculate_canonical_statistics_t(spec, date, prices_df, rf_df)
         np.testing.assert_allclose(t.to_numpy().ravel(), g[f"{tag}_t"], rtol=1e-11, atol=1e-16)
         wts = pc.calculate_jeffreys_portfolio(spec, date, prices_df, rf_df)
-        np.testing.assert_allclose(wts["Weight"].to_numpy(), g[f"{tag}_weights"], rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(wts["Weight"].to_numpy(), g[f"{tag}_weights"], rtol=1e-10, atol=1e-13)
 
 
 def test_out_of_scope_strategies_raise(pc):
@@ -113,7 +113,7 @@ def test_jorion_matches_reference(pc):
             spec = _spec("jorion", k, N, "daily", "daily")
             wts = pc.calculate_jorion_portfolio(spec, date, prices_df, rf_df)
             assert list(wts.index) == tickers and wts.index.name == "Stock"
-            np.testing.assert_allclose(wts["Weight"].to_numpy(), g[f"k{k}_n{N}_w{w}_weights"], rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(wts["Weight"].to_numpy(), g[f"k{k}_n{N}_w{w}_weights"], rtol=0, atol=1e-10)
 
 
 @pytest.mark.parametrize("name", ["backtest_k10_n60_daily_jorion", "backtest_k8_n30_weekly_monthly_jorion"])
@@ -124,9 +124,9 @@ def test_jorion_backtest_matches_reference(pc, name):
     days = md["stock_prices_df"].index
     spec = _spec("jorion", int(g["size"]), int(g["N"]), str(g["window_freq"]), str(g["rebal"]))
     res = pc.backtest_portfolio(spec, days[int(g["start_idx"])], days[-1], md)
-    np.testing.assert_allclose(res["portfolio_simple_returns_series"].to_numpy(), g["jorion_returns"], rtol=1e-7, atol=1e-10)
-    np.testing.assert_allclose(res["portfolio_turnover_series"].to_numpy(), g["jorion_turnover"], rtol=1e-7, atol=1e-10)
-    np.testing.assert_allclose(res["portfolio_weights_metrics_df"].to_numpy(), g["jorion_metrics"], rtol=1e-7, atol=1e-10,
+    np.testing.assert_allclose(res["portfolio_simple_returns_series"].to_numpy(), g["jorion_returns"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(res["portfolio_turnover_series"].to_numpy(), g["jorion_turnover"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(res["portfolio_weights_metrics_df"].to_numpy(), g["jorion_metrics"], rtol=1e-9, atol=1e-12,
                                equal_nan=True)
 
 

@@ -11,7 +11,10 @@ from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-WTOL = dict(rtol=1e-9, atol=1e-10)     # north_star: 1e-10 on the weights (fp64)
+# north_star: 1e-10 on the weights (fp64) - a FLAT absolute bound, no relative slack.  Observed on MI355X
+# (tools/parity_report.py, 58 shapes, k = 1 .. 2047, both strategies): max |hip - oracle| = 6.1e-12 at k = 2047,
+# <= 3.4e-13 everywhere else, 2.7e-14 at k = 100.
+WTOL = dict(rtol=0, atol=1e-10)
 
 
 @pytest.fixture(scope="module")
@@ -86,9 +89,9 @@ def test_hip_matches_oracle_all_tile_shapes(native, k, N, hf_days, strat):
     wts, status, aux = native.posterior_batch(strat, k, N, 5.0, **kw)
     assert (status == rstat).all()
     scale = np.abs(ref).max()
-    np.testing.assert_allclose(wts, ref, rtol=1e-8, atol=1e-10 * max(1.0, scale))
+    np.testing.assert_allclose(wts, ref, **WTOL)
     if strat == "conjugate":
-        np.testing.assert_allclose(aux[:, :6], raux[:, :6], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(aux[:, :6], raux[:, :6], rtol=1e-11, atol=1e-14)
 
 
 def test_rccl_gather_world_1(native):
@@ -193,11 +196,11 @@ def test_row_and_column_index_modes(native):
     ref, rstat, raux = oracle.posterior_batch("conjugate", k, N, 5.0, **kw)
     wts, status, aux = native.posterior_batch("conjugate", k, N, 5.0, **kw)
     assert (status == rstat).all()
-    np.testing.assert_allclose(wts, ref, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(wts, ref, **WTOL)
     kwj = dict(panel=inp["panel"], start=None, n_r=n_r, row_idx=rows, n_rows=n_rows, col_idx=cols, rf_adj=rf)
     refj, _, _ = oracle.posterior_batch("jeffreys", k, N, 5.0, **kwj)
     wj, sj, _ = native.posterior_batch("jeffreys", k, N, 5.0, **kwj)
-    np.testing.assert_allclose(wj, refj, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(wj, refj, **WTOL)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -221,7 +224,7 @@ def test_tiled_path_matches_reference_golden(native, name, strat):
         hf_start=np.zeros(1, np.int64), m=m, w0=g[f"w0_{strat}_w0"][None, :],
         n0=np.array([float(g[f"w0_{strat}_n0"])]), col_idx=order[None, :])
     assert status[0] == 0
-    np.testing.assert_allclose(wts[0], g[f"w0_{strat}_weights"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(wts[0], g[f"w0_{strat}_weights"], **WTOL)
     assert aux[0, 2] == pytest.approx(float(g[f"w0_{strat}_c"]), rel=1e-11)
     assert aux[0, 4] == pytest.approx(float(g[f"w0_{strat}_q1"]), rel=1e-8)
 
@@ -241,9 +244,9 @@ def test_tiled_path_matches_oracle(native, k, N, hf_days, strat):
     wts, status, aux = native.posterior_batch(strat, k, N, 5.0, **kw)
     assert (status == rstat).all()
     scale = max(1.0, np.abs(ref).max())
-    np.testing.assert_allclose(wts, ref, rtol=1e-7, atol=1e-10 * scale)
+    np.testing.assert_allclose(wts, ref, **WTOL)
     if strat == "conjugate":
-        np.testing.assert_allclose(aux[:, :6], raux[:, :6], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(aux[:, :6], raux[:, :6], rtol=1e-11, atol=1e-14)
 
 
 @pytest.mark.parametrize("k,N", [(3, 12), (10, 60), (33, 80), (100, 250), (239, 300), (300, 400)])
@@ -262,12 +265,12 @@ def test_shift_and_plain_gram_match_oracle(native, k, N):
     got, status, _ = native.posterior_batch("jeffreys", k, N, 1.0, **kw, rhs=rhs, shift=shift,
                                             flags=native.FLAG_NO_CENTER)
     assert (status == 0).all()
-    np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(got, ref, **WTOL)
     # Jeffreys scatter + shift, default right-hand side t
     ref, rstat, _ = oracle.posterior_batch("jeffreys", k, N, 5.0, **kw, shift=shift)
     got, status, _ = native.posterior_batch("jeffreys", k, N, 5.0, **kw, shift=shift)
     assert (status == 0).all()
-    np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(got, ref, **WTOL)
 
 
 def test_shift_is_rejected_where_it_does_not_apply(native):
@@ -322,7 +325,7 @@ def test_price_front_end_matches_return_panels(native, k, N):
     same, _, _ = native.posterior_batch("conjugate", k, N, 5.0, panel=Lp, hf_panel=Lh, **common)
     np.testing.assert_allclose(got, same, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(same).max()))
     ref, _, _ = oracle.posterior_batch_c("conjugate", k, N, 5.0, panel=Lp, hf_panel=Lh, **common)
-    np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(got, ref, **WTOL)
     with pytest.raises(Exception, match="outside the panel"):      # windows are checked against the RETURN rows
         native.posterior_batch("conjugate", k, N, 5.0, panel=P, hf_panel=H, ret_pairs=(pairs(len(P))[0][:-3], pairs(len(P))[1][:-3]),
                                hf_ret_pairs=pairs(len(H)), **common)
@@ -347,9 +350,9 @@ def test_contiguous_layout_with_ragged_rows_and_risk_free_adjustment(native, k, 
     ref, rstat, raux = oracle.posterior_batch(strat, k, N, 5.0, **kw)
     got, status, aux = native.posterior_batch(strat, k, N, 5.0, **kw)
     assert (status == rstat).all()
-    np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(got, ref, **WTOL)
     if strat == "conjugate":
-        np.testing.assert_allclose(aux[:, :6], raux[:, :6], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(aux[:, :6], raux[:, :6], rtol=1e-11, atol=1e-14)
 
 
 @pytest.mark.parametrize("k,N,hf_days", [(7, 30, 1), (31, 70, 1), (100, 250, 1), (130, 200, 2), (200, 250, 3), (239, 260, 4),

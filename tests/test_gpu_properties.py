@@ -93,8 +93,8 @@ def test_full_size_properties(native, cfg, W):
     # sampled oracle check on windows of the full batch
     sub = {key: (val[sample] if key in ("start", "hf_start", "w0", "n0") else val) for key, val in kw.items()}
     ref, rstat, raux = oracle.posterior_batch_c("conjugate", k, N, 5.0, n_r=shp["n_r"], m=shp["m"], **sub)
-    np.testing.assert_allclose(wts[sample], ref, rtol=1e-8, atol=1e-10 * max(1.0, np.abs(ref).max()))
-    np.testing.assert_allclose(aux[sample, :6], raux[:, :6], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(wts[sample], ref, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(aux[sample, :6], raux[:, :6], rtol=1e-11, atol=1e-14)
 
 
 def test_asset_permutation_equivariance_full_size(native):
