@@ -59,6 +59,9 @@ extern "C" {
 #define TP_FLAG_NO_CENTER 2      /* Jeffreys strategy on the plain Gram matrix T = X'X (no - t t'/N term):
                                    (n-1) S + n xbar xbar' of ref:924 is exactly T */
 
+#define TP_FLAG_NO_SHARED_GRAM 4  /* do not share Gram sums between overlapping windows (contiguous layout): every
+                                   window pushes all its rows through the MFMAs, as the index layout always does */
+
 typedef struct tp_handle_s* tp_handle_t;
 typedef struct tp_batch_s* tp_batch_t;
 

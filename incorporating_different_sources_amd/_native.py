@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
 
 import numpy as np
@@ -27,6 +28,7 @@ STATUS_OK, STATUS_NOT_PD, STATUS_NONFINITE, STATUS_BAD_DENOM = 0, 1, 2, 3
 AUX_STRIDE = 8
 FLAG_CENTER_BY_ROWS = 1
 FLAG_NO_CENTER = 2
+FLAG_NO_SHARED_GRAM = 4
 UNIQUE_ID_BYTES = 128
 
 # every symbol include/tangency_posterior.h declares (checked by tests/test_cabi_symbols.py)
@@ -191,6 +193,7 @@ class Device:
 
     def __init__(self, device_id: int = 0):
         self._h = c_void_p()
+        self._batches = weakref.WeakSet()
         rc = lib.tp_create(int(device_id), ctypes.byref(self._h))
         if rc != TP_OK:
             raise TangencyError(rc, lib.tp_last_error(None).decode())
@@ -202,6 +205,8 @@ class Device:
 
     def close(self):
         if self._h:
+            for b in list(self._batches):      # a batch must not outlive its handle (tp_batch_destroy dereferences it)
+                b.close()
             lib.tp_destroy(self._h)
             self._h = c_void_p()
 
@@ -292,6 +297,7 @@ class Batch:
         self.W, self.k, self.n_r, self.m = int(W), int(k), int(n_r), int(m)
         self._b = c_void_p()
         dev._check(lib.tp_batch_create(dev._h, ctypes.byref(self.params), self.W, ctypes.byref(self._b)))
+        dev._batches.add(self)
         self._keep = None
 
     def close(self):

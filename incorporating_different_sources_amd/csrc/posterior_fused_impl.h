@@ -375,9 +375,10 @@ __device__ __forceinline__ void store_chunk(double* __restrict__ buf, const doub
 // tiles of wave WV that satisfy `pick(I,J)`.  `lanebase` = buf + fq*LDX + fr, so every operand is
 // one ds_read_b64 at an immediate offset.
 template <class C, int WV, int NROWS, bool NEG, class Pick>
-__device__ __forceinline__ void mfma_tiles(const double* __restrict__ lanebase, d4 (&acc)[C::SLOTS], Pick pick) {
+__device__ __forceinline__ void mfma_tiles(const double* __restrict__ lanebase, d4 (&acc)[C::SLOTS], Pick pick,
+                                           int ksteps = NROWS / 4) {
 #pragma clang loop unroll_count(tp_kstep_unroll)
-    for (int s4 = 0; s4 < NROWS / 4; ++s4) {
+    for (int s4 = 0; s4 < ksteps; ++s4) {
         for_tiles<C, WV>([&](auto sc, auto Ic, auto Jc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
             if (pick(I, J)) {
@@ -395,9 +396,12 @@ __device__ __forceinline__ void mfma_tiles(const double* __restrict__ lanebase, 
 // with the per-chunk vector work cut to the bone - four loop-carried lane values (row offset, its clamp,
 // the last column group's offset, the LDS write address) instead of re-deriving everything from the thread
 // id, the row clamp as ONE v_min, masks only in the ragged last chunk.
-template <class C, bool HF, int FIX>
+struct NoChunkHook { __device__ __forceinline__ void operator()(int) const {} };
+
+// `before_chunk(ch)` runs before the MFMAs of chunk ch (the prefix kernel stores the running sums there).
+template <class C, bool HF, int FIX, class Hook = NoChunkHook>
 __device__ __forceinline__ void gram_phase_lean(const RowSource& src, int k, double* lds, int tid0, int wv,
-                                                d4 (&acc)[C::SLOTS]) {
+                                                d4 (&acc)[C::SLOTS], Hook before_chunk = Hook{}) {
     constexpr int kI = C::NT - 1;
     const int nchunks = (src.count + C::CH - 1) / C::CH;
     const bool has_sub = !HF && src.sub_row != nullptr;
@@ -483,8 +487,12 @@ __device__ __forceinline__ void gram_phase_lean(const RowSource& src, int k, dou
         if (more) load();                             // global loads in flight under the MFMAs
         __builtin_amdgcn_sched_barrier(0);            // the scheduler must not sink these loads below the MFMA block
         const double* lanebase = cur + fq * C::LDX + fr;
+        before_chunk(ch);
+        // the ragged last chunk runs only the 4-row k-steps that hold rows (the rest of the staged chunk is zeros)
+        const int rows_here = src.count - ch * C::CH;
+        const int ksteps = rows_here >= C::CH ? C::CH / 4 : (rows_here + 3) >> 2;
         wave_sel<C::NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
-            mfma_tiles<C, decltype(wc)::value, C::CH, false>(lanebase, acc, [](int, int) { return true; });
+            mfma_tiles<C, decltype(wc)::value, C::CH, false>(lanebase, acc, [](int, int) { return true; }, ksteps);
         });
         if (more) store(nxt, ch + 1);
         __syncthreads();
@@ -776,8 +784,57 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
         ds.sub_row = A.rf_adj ? A.rf_adj + w * (long long)A.n_r : nullptr;
         ds.count = A.n_rows ? A.n_rows[w] : A.n_r;
         ds.off32 = (A.panel_off32 & (ds.ridx ? 1 : 2)) != 0;
-        if constexpr (LEAN) gram_phase_lean<C, false, FIX>(ds, k, lds, tid0, wv, acc);
-        else gram_phase<C, false, FIX>(ds, cols, k, lds, tid0, wv, acc, TP_LOOPSTAMP_PTR);
+        if constexpr (LEAN) {
+            // Shared Gram prefixes (tp_kargs_t.prefix, prefix_gram_kernel below): the rows of this window that form
+            // whole aligned C::CH-row blocks of the panel come as the difference of two running sums that EVERY
+            // window over the panel shares; only the < C::CH rows in front of the first whole block and behind the
+            // last one go through the MFMAs here.  Rolling windows overlap almost entirely (stride 1: 248 of 249
+            // rows), so the daily Gram of a window costs ~5 k-steps instead of 63.  The decomposition depends on the
+            // window's panel rows only - never on which other windows are in the batch.
+            constexpr int BLK = C::CH;
+            const long long b0 = (ds.first + BLK - 1) / BLK, b1 = (ds.first + ds.count) / BLK;
+            const bool shared = A.prefix != nullptr && b1 > b0;
+            const int lo_count = shared ? (int)(BLK * b0 - ds.first) : ds.count;
+            const int hi_count = shared ? (int)(ds.first + ds.count - BLK * b1) : 0;
+#pragma nounroll
+            for (int e = 0; e < 2; ++e) {                  // e = 0: the rows in front (or all rows), e = 1: the rows behind
+                RowSource part = ds;
+                part.first = e ? BLK * b1 : ds.first;
+                part.count = e ? hi_count : lo_count;
+                if (part.count > 0) gram_phase_lean<C, false, FIX>(part, k, lds, tid0, wv, acc);
+            }
+            if (shared) {
+                // running sums restart every TP_PREFIX_SEG blocks (bounded cancellation): slot g (SEG+1) + l
+                // holds the sum of blocks [g SEG, g SEG + l) of segment g, l = 0 .. SEG
+                constexpr int SEG = TP_PREFIX_SEG;
+                const long long gS = b0 / SEG, gE = (b1 - 1) / SEG;
+                const long long slotS = gS * (SEG + 1) + (b0 - gS * SEG);
+                const long long slotE = gE * (SEG + 1) + (b1 - gE * SEG);
+                const long long slotT = gS * (SEG + 1) + SEG;                  // whole first segment (gE = gS + 1)
+                const bool span = gE != gS;
+                TP_LANE_CONSTANTS();
+                constexpr long long TILE = 4 * 64, SLOT = (long long)C::NTILES * TILE;
+                wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
+                    constexpr int WV = decltype(wc)::value;
+                    for_tiles<C, WV>([&](auto sc_, auto, auto) __attribute__((always_inline)) {
+                        constexpr int s = decltype(sc_)::value;
+                        constexpr long long t = s * NW + WV;
+                        const double* pS = A.prefix + slotS * SLOT + t * TILE + lane;
+                        const double* pE = A.prefix + slotE * SLOT + t * TILE + lane;
+                        const double* pT = A.prefix + slotT * SLOT + t * TILE + lane;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            double mid = pE[64 * r];
+                            if (span) mid += pT[64 * r] - pS[64 * r];
+                            else mid -= pS[64 * r];
+                            acc[s][r] += mid;
+                        }
+                    });
+                });
+            }
+        } else {
+            gram_phase<C, false, FIX>(ds, cols, k, lds, tid0, wv, acc, TP_LOOPSTAMP_PTR);
+        }
     }
 
     {
@@ -1151,6 +1208,47 @@ __global__ void __launch_bounds__(64 * NW, tp_min_waves_for_tiles(NT)) posterior
 #endif
 }
 
+// Running Gram sums of the daily panel over aligned blocks of C::CH rows, restarted every TP_PREFIX_SEG blocks: one
+// workgroup per segment walks its blocks with the staging and MFMA loop of the window kernel (same tile ownership,
+// same accumulator layout) and stores the accumulators BEFORE each block - slot l of segment g = sum of the
+// blocks [g SEG, g SEG + l) - and once more after the last one.  Layout [slot][tile][4][64] doubles: a window's wave
+// loads its tiles' registers with coalesced 512-byte reads.  Column k of every block is the ones column, so the
+// border column of the sums is t = X'1 and the corner the row count, exactly as in phase D.
+template <int NT, int NW>
+__global__ void __launch_bounds__(64 * NW) prefix_gram_kernel(const tp_kargs_t A, double* __restrict__ out, const int nblk) {
+    using C = Cfg<NT, NW>;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid0 = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    constexpr int SEG = TP_PREFIX_SEG, BLK = C::CH;
+    const long long g = blockIdx.x;
+    const long long bfirst = g * SEG;
+    const int nb = (int)((nblk - bfirst < SEG) ? (nblk - bfirst) : SEG);
+    if (nb <= 0) return;
+    d4 acc[C::SLOTS];
+    static_for<0, C::SLOTS>([&](auto sc_) __attribute__((always_inline)) { acc[decltype(sc_)::value] = d4{0.0, 0.0, 0.0, 0.0}; });
+    RowSource ds;
+    ds.base = A.panel; ds.ld = A.panel_ld; ds.ridx = nullptr; ds.first = bfirst * BLK; ds.sub_row = nullptr;
+    ds.count = nb * BLK; ds.off32 = true;
+    constexpr long long TILE = 4 * 64, SLOT = (long long)C::NTILES * TILE;
+    double* seg = out + g * (SEG + 1) * SLOT;
+    auto store_slot = [&](int l) __attribute__((always_inline)) {
+        const int lane = fresh(tid0) & 63;
+        wave_dispatch<NW>(wv, [&](auto wc) __attribute__((always_inline)) {
+            constexpr int WV = decltype(wc)::value;
+            for_tiles<C, WV>([&](auto sc_, auto, auto) __attribute__((always_inline)) {
+                constexpr int s = decltype(sc_)::value;
+                constexpr long long t = s * NW + WV;
+                double* p = seg + l * SLOT + t * TILE + lane;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[64 * r] = acc[s][r];
+            });
+        });
+    };
+    gram_phase_lean<C, false, -1>(ds, A.k, lds, tid0, wv, acc, store_slot);
+    store_slot(nb);
+}
+
 // the contiguous layout the LEAN kernel is built for: no index arrays, window-relative 32-bit offsets
 inline bool tp_layout_is_lean(const tp_kargs_t& a) {
     if (a.col_idx || a.row_idx || !(a.panel_off32 & 2)) return false;
@@ -1175,8 +1273,25 @@ hipError_t launch_variant(const tp_kargs_t& a, int grid, hipStream_t stream, tp_
 
 template <int NT, int NW>
 hipError_t launch_one(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info) {
-    return tp_layout_is_lean(a) ? launch_variant<NT, NW, true>(a, grid, stream, info)
-                                : launch_variant<NT, NW, false>(a, grid, stream, info);
+    using C = Cfg<NT, NW>;
+    static_assert(C::CH == TP_PREFIX_BLOCK_ROWS(NT), "posterior_kernels.h: block rows of the shared Gram prefixes");
+    if (!tp_layout_is_lean(a)) return launch_variant<NT, NW, false>(a, grid, stream, info);
+    if (a.prefix != nullptr) {
+        // the shared running sums first, on the same stream: part of every run, nothing is kept between runs
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute((const void*)prefix_gram_kernel<NT, NW>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        const int nseg = (a.prefix_nblk + TP_PREFIX_SEG - 1) / TP_PREFIX_SEG;
+        hipLaunchKernelGGL((prefix_gram_kernel<NT, NW>), dim3(nseg), dim3(C::NTHREADS), C::LDS_BYTES, stream, a,
+                           (double*)a.prefix, a.prefix_nblk);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return launch_variant<NT, NW, true>(a, grid, stream, info);
 }
 
 template <int NT, int NW>

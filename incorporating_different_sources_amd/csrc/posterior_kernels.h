@@ -22,6 +22,10 @@ struct tp_kargs_t {
     const int* hf_count;
     const double* w0;
     const double* n0;
+    const double* prefix; // optional (contiguous layout, no rf_adj): workspace of the shared running Gram sums of the
+                          // daily panel, [nseg (TP_PREFIX_SEG + 1)][tiles][4][64] doubles (posterior_fused_impl.h);
+                          // filled by every launch before the window kernel reads it
+    int prefix_nblk;      // whole TP_PREFIX_BLOCK_ROWS-row blocks of the panel
     const double* rhs;    // optional [W x k]: replaces the border column before the factorisation
     const double* shift;  // optional [W x 2], Jeffreys only: (d, e) adds d I + e 1 1' to the matrix that is factorised
     double* weights;
@@ -42,6 +46,18 @@ struct tp_kargs_t {
 };
 
 struct tp_launch_info_t { int grid, block, lds_bytes, ntile; };
+
+// Shared Gram prefixes of the register-tile path: aligned blocks of the staged chunk's rows (16; 32 with eight waves,
+// NT >= 13), running sums restarted every TP_PREFIX_SEG blocks.
+#define TP_PREFIX_SEG 16
+#define TP_PREFIX_BLOCK_ROWS(nt) ((nt) <= 12 ? 16 : 32)
+inline size_t tp_fused_prefix_bytes(int k, long long panel_rows, int* nblk_out) {
+    const int nt = (k + 1 + 15) / 16;
+    const long long nblk = panel_rows / TP_PREFIX_BLOCK_ROWS(nt);
+    const long long nseg = (nblk + TP_PREFIX_SEG - 1) / TP_PREFIX_SEG;
+    if (nblk_out) *nblk_out = (int)nblk;
+    return sizeof(double) * (size_t)(nseg * (TP_PREFIX_SEG + 1)) * (size_t)(nt * (nt + 1) / 2) * 256;
+}
 
 // register-tile fused kernel (posterior_fused.hip): k <= tp_fused_max_assets()
 int tp_fused_max_assets(void);

@@ -60,6 +60,8 @@ struct tp_batch_s {
     DevBuf panel, start, row_idx, n_rows, col_idx, rf_adj, hf_panel, hf_start, hf_row_idx, hf_count, w0, n0;
     DevBuf weights, status, aux, dbg, gather_w, gather_s, weights2, status2, stamps, rhs, out_rhs, shift;
     DevBuf fe_prices, fe_num, fe_den, fe_hf_prices, fe_hf_num, fe_hf_den;   // price front-end staging (freed after a synchronous upload)
+    DevBuf prefix;                                            // shared Gram prefixes of the daily panel (register-tile path)
+    int prefix_nblk = 0;                                      // > 0: the layout qualifies (decided at upload)
     DevBuf t_arena, t_rinv, t_ybar, t_zc, t_scal, t_flags;   // large-k path workspace
     int64_t tiled_capacity = 0;                               // windows in flight per sub-batch
     bool uploaded = false;
@@ -162,6 +164,8 @@ tp_kargs_t make_kargs(tp_batch_t b) {
     a.hf_count = (const int*)b->hf_count.p;
     a.w0 = (const double*)b->w0.p;
     a.n0 = (const double*)b->n0.p;
+    a.prefix = b->prefix_nblk > 0 ? (const double*)b->prefix.p : nullptr;
+    a.prefix_nblk = b->prefix_nblk;
     a.rhs = (const double*)b->rhs.p;
     a.shift = (const double*)b->shift.p;
     a.center_rows = (b->p.flags & TP_FLAG_NO_CENTER) ? 2 : (b->p.flags & TP_FLAG_CENTER_BY_ROWS) ? 1 : 0;
@@ -472,10 +476,33 @@ int tp_batch_destroy(tp_batch_t b) {
     for (DevBuf* d : {&b->fe_prices, &b->fe_num, &b->fe_den, &b->fe_hf_prices, &b->fe_hf_num, &b->fe_hf_den}) release(*d);
     DevBuf* all[] = {&b->panel, &b->start, &b->row_idx, &b->n_rows, &b->col_idx, &b->rf_adj, &b->hf_panel, &b->hf_start,
                      &b->hf_row_idx, &b->hf_count, &b->w0, &b->n0, &b->weights, &b->status, &b->aux, &b->dbg,
-                     &b->gather_w, &b->gather_s, &b->weights2, &b->status2, &b->stamps, &b->rhs, &b->out_rhs, &b->shift, &b->t_arena, &b->t_rinv, &b->t_ybar, &b->t_zc,
+                     &b->gather_w, &b->gather_s, &b->weights2, &b->status2, &b->stamps, &b->rhs, &b->out_rhs, &b->shift, &b->prefix, &b->t_arena, &b->t_rinv, &b->t_ybar, &b->t_zc,
                      &b->t_scal, &b->t_flags};
     for (DevBuf* d : all) release(*d);
     delete b;
+    return TP_OK;
+}
+
+// Rolling windows over one shared panel overlap almost entirely; the register-tile path then takes the whole aligned
+// row blocks of every window from running Gram sums of the panel that all windows share (posterior_fused_impl.h,
+// prefix_gram_kernel) instead of pushing every row of every window through the MFMAs.  Qualifies: contiguous windows
+// (start[]), no column gather, no per-row risk-free adjustment, k in the register-tile range, and windows that
+// together cover the panel at least three times.  The sums are recomputed by EVERY tp_batch_run (nothing is kept
+// between runs); TP_FLAG_NO_SHARED_GRAM switches the scheme off.
+static int plan_shared_gram(tp_batch_t b, const tp_inputs_t* in) {
+    tp_handle_t h = b->h;
+    b->prefix_nblk = 0;
+    const tp_params_t& p = b->p;
+    if ((p.flags & TP_FLAG_NO_SHARED_GRAM) || getenv("TP_NO_SHARED_GRAM")) return TP_OK;
+    if (p.k > tp_fused_max_assets() || in->row_idx || in->col_idx || in->rf_adj || !in->start) return TP_OK;
+    const long long rows = in->ret_num ? in->ret_rows : in->panel_rows;
+    int nblk = 0;
+    const size_t bytes = tp_fused_prefix_bytes(p.k, rows, &nblk);
+    if (nblk < 2 || (double)b->W * p.n_r < 3.0 * (double)rows) return TP_OK;
+    if ((size_t)in->panel_ld * 8 * 4096 >= (1ull << 32)) return TP_OK;      // 32-bit offsets inside a segment
+    int rc = ensure(h, b->prefix, bytes);
+    if (rc != TP_OK) return rc;
+    b->prefix_nblk = nblk;
     return TP_OK;
 }
 
@@ -538,6 +565,8 @@ static int upload_common(tp_batch_t b, const tp_inputs_t* in, hipStream_t st, bo
 #undef PUT
     b->panel_ld = in->panel_ld;
     b->hf_ld = conj ? in->hf_ld : 0;
+    rc = plan_shared_gram(b, in);
+    if (rc != TP_OK) return rc;
     HIP_TRY(h, hipEventRecord(e1, st));
     if (wait) {
         HIP_TRY(h, hipEventSynchronize(e1));

@@ -41,11 +41,18 @@ def partition(W: int, world: int) -> list[tuple[int, int]]:
     return out
 
 
+# The register-tile kernel sums the whole aligned row blocks of a window through running sums over the panel that
+# restart every 16 blocks of 16 (or 32) rows; a shard that uploads only part of a panel must cut it at a multiple of
+# 512 rows, so that every window sees the same blocks and restarts - hence bit-identical weights - as in the full panel.
+PANEL_CUT_ALIGN = 512
+
+
 def needed_rows(start: np.ndarray, count: int) -> tuple[int, int]:
-    """Panel row span [lo, hi) that a shard with contiguous windows touches (to upload only that)."""
+    """Panel row span [lo, hi) that a shard with contiguous windows touches (to upload only that); lo is aligned
+    down to PANEL_CUT_ALIGN rows."""
     if len(start) == 0:
         return 0, 0
-    return int(start.min()), int(start.max()) + int(count)
+    return (int(start.min()) // PANEL_CUT_ALIGN) * PANEL_CUT_ALIGN, int(start.max()) + int(count)
 
 
 def slice_window_inputs(inputs: dict, lo: int, hi: int, n_r: int, m: int) -> dict:

@@ -27,7 +27,7 @@ def test_slice_window_inputs_rebases_offsets():
     from incorporating_different_sources_amd import synthetic
     inp = synthetic.make_kernel_inputs(5, 20, 11, seed=1)
     s = shard.slice_window_inputs(inp, 4, 9, inp["n_r"], inp["m"])
-    assert s["W"] == 5 and s["start"][0] == 0 and s["hf_start"][0] == 0
+    assert s["W"] == 5 and s["start"][0] == 4 and s["hf_start"][0] == 4 * 78 % 512     # cuts at multiples of 512 rows
     for i, w in enumerate(range(4, 9)):
         a = inp["panel"][inp["start"][w]: inp["start"][w] + inp["n_r"]]
         b = s["panel"][s["start"][i]: s["start"][i] + inp["n_r"]]
@@ -35,7 +35,7 @@ def test_slice_window_inputs_rebases_offsets():
         a = inp["hf_panel"][inp["hf_start"][w]: inp["hf_start"][w] + inp["m"]]
         b = s["hf_panel"][s["hf_start"][i]: s["hf_start"][i] + inp["m"]]
         assert np.array_equal(a, b)
-    assert s["panel"].shape[0] == (8 - 4) + inp["n_r"]
+    assert s["panel"].shape[0] == 4 + (8 - 4) + inp["n_r"]
 
 
 def _free_port():
