@@ -15,7 +15,7 @@ for grp in \
   "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_VALU_MFMA_COEXEC_CYCLES" \
   "SQ_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVES SQ_LEVEL_WAVES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_THREAD_CYCLES_VALU"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp -f csv -d "$OUT/pass$i" -- python3 "${GRAFT_REPO_ROOT:-$PWD}/bench.py" $BENCH_ARGS --no-cpu-baseline > "$OUT/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$OUT/pass$i.log"; }
+  rocprofv3 --pmc $grp -f csv -d "$OUT/pass$i" -- python3 "${GRAFT_REPO_ROOT:-$PWD}/bench.py" $BENCH_ARGS --no-cpu-baseline --no-end-to-end > "$OUT/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$OUT/pass$i.log"; }
 done
 python3 - "$OUT" "$KERNEL" <<'PY'
 import csv, glob, sys, collections
