@@ -812,8 +812,10 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
                 const long long slotE = gE * (SEG + 1) + (b1 - gE * SEG);
                 const long long slotT = gS * (SEG + 1) + SEG;                  // whole first segment (gE = gS + 1)
                 const bool span = gE != gS;
+                const int nmid = span ? (int)(gE - gS - 1) : 0;                // whole segments between the two ends
                 TP_LANE_CONSTANTS();
                 constexpr long long TILE = 4 * 64, SLOT = (long long)C::NTILES * TILE;
+                constexpr long long tstride = (SEG + 1) * SLOT;                // from one segment's total to the next one's
                 wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
                     constexpr int WV = decltype(wc)::value;
                     for_tiles<C, WV>([&](auto sc_, auto, auto) __attribute__((always_inline)) {
@@ -825,7 +827,8 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             double mid = pE[64 * r];
-                            if (span) mid += pT[64 * r] - pS[64 * r];
+                            for (int q = nmid; q >= 1; --q) mid += pT[64 * r + q * tstride];   // whole segments in between,
+                            if (span) mid += pT[64 * r] - pS[64 * r];                          // the last one first
                             else mid -= pS[64 * r];
                             acc[s][r] += mid;
                         }

@@ -78,7 +78,9 @@ struct tp_tiled_ws_t {
 };
 int tp_tiled_max_assets(void);
 void tp_tiled_geometry(int k, int* KP, int* NS, int* NSB);
-hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStream_t stream);
+hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStream_t stream, bool build_prefix);
+// bytes of the shared running Gram sums of the daily panel in the tiled layout (16-row blocks, TP_PREFIX_SEG per segment)
+size_t tp_tiled_prefix_bytes(int k, long long panel_rows, int* nblk_out);
 
 // price front-end (returns_frontend.hip): out[i][c] = log(prices[num[i]][c] / prices[den[i]][c]), NaN -> 0
 hipError_t tp_log_return_rows_launch(const double* prices, int ld, const int* num, const int* den, long long n_out,

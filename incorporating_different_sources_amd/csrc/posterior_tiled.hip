@@ -63,6 +63,9 @@ __device__ __forceinline__ void pair_decode(int p, int n, int& a, int& b) {
     a = i; b = i + rem;
 }
 
+// inverse of pair_decode: row-major number of the upper-triangle pair (a, b), a <= b < n
+__device__ __forceinline__ long long pair_index(int a, int b, int n) { return (long long)a * n - (long long)a * (a - 1) / 2 + (b - a); }
+
 // XCD-aware mapping of a 1-D grid to (window, tile) for the kernels that run SEVERAL workgroups per window.
 // MI355X deals consecutive workgroup ids round-robin to its 8 XCDs, each with its own 4 MB L2.  With
 // (window, tile) = (blockIdx.x, blockIdx.y) the tiles of one window ran on one XCD but thousands of workgroups
@@ -399,8 +402,17 @@ __device__ __forceinline__ void gram64_lean_body(const tp_kargs_t& A, const tp_t
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
 
+    // Shared running sums of the daily panel (tiled_prefix_kernel; posterior_fused_impl.h has the register-tile
+    // form): the window's whole aligned CH-row blocks come as a difference of two sums every window shares, only the
+    // rows in front of the first whole block (`lo` of them) and behind the last one are staged here.
+    const long long dfirst = A.start ? A.start[w] : 0;
+    const long long pb0 = (dfirst + CH - 1) / CH, pb1 = (dfirst + nr) / CH;
+    const bool shared = A.prefix != nullptr && !dridx && pb1 > pb0;
+    const int lo = shared ? (int)(CH * pb0 - dfirst) : nr;            // staged daily rows r < lo: window rows r
+    const int djump = shared ? (int)(CH * pb1 - dfirst) - lo : 0;     //                  r >= lo: window rows r + djump
+    const int nrs = shared ? lo + (int)(dfirst + nr - CH * pb1) : nr; // staged daily rows
     const int hchunks = (mm + CH - 1) / CH;
-    const int nchunks = hchunks + (nr + CH - 1) / CH;
+    const int nchunks = hchunks + (nrs + CH - 1) / CH;
     double v[8];
     double rowc = 0.0;      // per-row constant: border entry (intraday) / risk-free adjustment (daily)
     auto load = [&](int ch) __attribute__((always_inline)) {
@@ -413,7 +425,8 @@ __device__ __forceinline__ void gram64_lean_body(const tp_kargs_t& A, const tp_t
             for (int i = 0; i < 8; ++i) v[i] = *(const double*)(hub + (size_t)(ro + co[i]));
         } else {
             const int r = (ch - hchunks) * CH + srow;
-            const int rc = r < nr ? r : nr - 1;
+            int rc = r < nrs ? r : nrs - 1;
+            rc += rc >= lo ? djump : 0;
             const unsigned ro = __umul24(dridx ? (unsigned)dridx[rc] : (unsigned)rc, dld8);
             rowc = rf ? rf[rc] : 0.0;
 #pragma unroll
@@ -441,8 +454,8 @@ __device__ __forceinline__ void gram64_lean_body(const tp_kargs_t& A, const tp_t
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = cval[i] ? v[i] : (cbord[i] ? 1.0 : 0.0);   // border: ones -> t
             }
-            if ((ch - hchunks + 1) * CH > nr) {
-                const bool rowv = (ch - hchunks) * CH + srow < nr;
+            if ((ch - hchunks + 1) * CH > nrs) {
+                const bool rowv = (ch - hchunks) * CH + srow < nrs;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = rowv ? v[i] : 0.0;
             }
@@ -469,11 +482,125 @@ __device__ __forceinline__ void gram64_lean_body(const tp_kargs_t& A, const tp_t
         if (more) store(nxt, ch + 1);
         __syncthreads();
     }
+    if (shared) {
+        // slot g (SEG+1) + l = sum of blocks [g SEG, g SEG + l) of segment g (running sums restart every SEG blocks)
+        constexpr int SEG = TP_PREFIX_SEG;
+        const long long gS = pb0 / SEG, gE = (pb1 - 1) / SEG;
+        const long long slotS = gS * (SEG + 1) + (pb0 - gS * SEG);
+        const long long slotE = gE * (SEG + 1) + (pb1 - gE * SEG);
+        const long long slotT = gS * (SEG + 1) + SEG;
+        const bool span = gE != gS;
+        const long long ntile = (long long)ws.NS * (ws.NS + 1) / 2;
+        const long long tile = pair_index(SI, SJ, ws.NS);
+        const double* pS = A.prefix + (slotS * ntile + tile) * (SB * SB) + wv * 1024 + lane;
+        const double* pE = A.prefix + (slotE * ntile + tile) * (SB * SB) + wv * 1024 + lane;
+        const double* pT = A.prefix + (slotT * ntile + tile) * (SB * SB) + wv * 1024 + lane;
+        const long long tstride = (SEG + 1) * ntile * (SB * SB);      // from one segment's total to the next one's
+        const int nmid = span ? (int)(gE - gS - 1) : 0;               // whole segments between the first and the last
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (b * 4 + r) * 64;
+                double mid = pE[o];
+                for (int q = nmid; q >= 1; --q) mid += pT[o + q * tstride];      // fixed order: last whole segment first
+                if (span) mid += pT[o] - pS[o];
+                else mid -= pS[o];
+                acc[b][r] += mid;
+            }
+    }
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             M[(long long)(64 * SI + 16 * wv + fq + 4 * r) * KP + 64 * SJ + 16 * b + fr] = acc[b][r];
+}
+
+// Running Gram sums of the daily panel for the tiled path: one workgroup per (segment of TP_PREFIX_SEG blocks of CH
+// rows, 64 x 64 super-tile); it walks the segment's blocks like the daily half of the Gram kernel (ones in the border
+// column, zeros beyond) and stores its accumulators before every block and once after the last: slot l of segment
+// g = sum of blocks [g SEG, g SEG + l).  Layout [slot][super-tile pair][wave][16-column group][4][64].
+template <bool EDGE>
+__device__ __forceinline__ void prefix64_body(const tp_kargs_t& A, const tp_tiled_ws_t& ws, double* lds, double* out,
+                                              const long long g, const int nb, const long long tile, const int SI, const int SJ) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int k = A.k;
+    constexpr int SEG = TP_PREFIX_SEG;
+    const char* dub = (const char*)(A.panel + g * SEG * CH * (long long)A.panel_ld);
+    const unsigned dld8 = (unsigned)A.panel_ld * 8u;
+    const int srow = tid >> 4, cb = tid & 15;
+    unsigned co[8];
+    bool cval[8], cbord[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int gc = 64 * ((i >> 2) ? SJ : SI) + cb + 16 * (i & 3);
+        cval[i] = !EDGE || gc < k;
+        cbord[i] = EDGE && gc == k;
+        co[i] = 8u * (unsigned)(cval[i] ? gc : k - 1);
+    }
+    d4 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
+    const long long ntile = (long long)ws.NS * (ws.NS + 1) / 2;
+    double* seg = out + (g * (SEG + 1) * ntile + tile) * (SB * SB) + wv * 1024 + lane;
+    auto store_slot = [&](int l) __attribute__((always_inline)) {
+        double* p = seg + (long long)l * ntile * (SB * SB);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[(b * 4 + r) * 64] = acc[b][r];
+    };
+    double v[8];
+    auto load = [&](int ch) __attribute__((always_inline)) {
+        const unsigned ro = __umul24((unsigned)(ch * CH + srow), dld8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = *(const double*)(dub + (size_t)(ro + co[i]));
+    };
+    auto store = [&](double* buf) __attribute__((always_inline)) {
+        if (EDGE) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = cval[i] ? v[i] : (cbord[i] ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) buf[srow * LDX + 64 * (i >> 2) + cb + 16 * (i & 3)] = v[i];
+    };
+    load(0); store(lds);
+    __syncthreads();
+    for (int ch = 0; ch < nb; ++ch) {
+        double* cur = lds + (ch & 1) * CH * LDX;
+        double* nxt = lds + ((ch + 1) & 1) * CH * LDX;
+        const bool more = ch + 1 < nb;
+        if (more) load(ch + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_slot(ch);
+        const double* lb = cur + fq * LDX + fr;
+#pragma unroll
+        for (int s4 = 0; s4 < CH / 4; ++s4) {
+            const double a = lb[4 * s4 * LDX + 16 * wv];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, lb[4 * s4 * LDX + 64 + 16 * b], acc[b], 0, 0, 0);
+        }
+        if (more) store(nxt);
+        __syncthreads();
+    }
+    store_slot(nb);
+}
+
+__global__ void __launch_bounds__(NTHREADS) tiled_prefix_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws, double* out, const int nblk) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * CH * LDX];
+    const long long ntile = (long long)ws.NS * (ws.NS + 1) / 2;
+    const long long g = blockIdx.x / ntile;
+    const int tile = (int)(blockIdx.x % ntile);
+    const long long bfirst = g * TP_PREFIX_SEG;
+    const int nb = (int)((nblk - bfirst < TP_PREFIX_SEG) ? (nblk - bfirst) : TP_PREFIX_SEG);
+    if (nb <= 0) return;
+    int SI, SJ;
+    pair_decode(tile, ws.NS, SI, SJ);
+    if (64 * SJ + 63 < A.k) prefix64_body<false>(A, ws, lds, out, g, nb, tile, SI, SJ);
+    else prefix64_body<true>(A, ws, lds, out, g, nb, tile, SI, SJ);
 }
 
 __global__ void __launch_bounds__(NTHREADS) tiled_gram_lean_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws) {
@@ -685,19 +812,33 @@ void tp_tiled_geometry(int k, int* KP, int* NS, int* NSB) {
 }
 
 // Whole pipeline for windows [a.w_first, a.w_first + a.w_count) (a.w_count <= ws capacity), on `stream`.
-hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStream_t stream) {
+size_t tp_tiled_prefix_bytes(int k, long long panel_rows, int* nblk_out) {
+    int KP, NS, NSB;
+    tp_tiled_geometry(k, &KP, &NS, &NSB);
+    const long long nblk = panel_rows / CH;
+    const long long nseg = (nblk + TP_PREFIX_SEG - 1) / TP_PREFIX_SEG;
+    if (nblk_out) *nblk_out = (int)nblk;
+    return sizeof(double) * (size_t)(nseg * (TP_PREFIX_SEG + 1)) * (size_t)(NS * (NS + 1) / 2) * SB * SB;
+}
+
+hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStream_t stream, bool build_prefix) {
     const int G = (int)a.w_count;
     if (G <= 0) return hipSuccess;
     const int NS = ws.NS, NSB = ws.NSB;
     const bool conj = a.strategy == 0;
+    // 32-bit offsets for both panels in the layout they come in (explicit rows: bit 0, contiguous: bit 1)?
+    const bool lean = (a.panel_off32 & (a.row_idx ? 1 : 2)) && (!conj || (a.hf_off32 & (a.hf_row_idx ? 1 : 2)));
+    if (build_prefix && a.prefix != nullptr && lean) {      // the shared running sums of the daily panel, once per run
+        const int nseg = (a.prefix_nblk + TP_PREFIX_SEG - 1) / TP_PREFIX_SEG;
+        hipLaunchKernelGGL(tiled_prefix_kernel, dim3((unsigned)(nseg * (NS * (NS + 1) / 2))), dim3(NTHREADS), 0, stream, a, ws,
+                           (double*)a.prefix, a.prefix_nblk);
+    }
     if (conj) {
         const int nci = (a.k + 63) / 64;
         if (nci <= 8) hipLaunchKernelGGL(tiled_prior_kernel<8>, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
         else if (nci <= 16) hipLaunchKernelGGL(tiled_prior_kernel<16>, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
         else hipLaunchKernelGGL(tiled_prior_kernel<32>, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
     }
-    // 32-bit offsets for both panels in the layout they come in (explicit rows: bit 0, contiguous: bit 1)?
-    const bool lean = (a.panel_off32 & (a.row_idx ? 1 : 2)) && (!conj || (a.hf_off32 & (a.hf_row_idx ? 1 : 2)));
     if (lean) hipLaunchKernelGGL(tiled_gram_lean_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws);
     else hipLaunchKernelGGL(tile64_kernel<MODE_GRAM>, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws, 0);
     if (!conj) hipLaunchKernelGGL(tiled_rank1_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws);

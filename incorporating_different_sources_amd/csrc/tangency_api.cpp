@@ -324,7 +324,7 @@ int launch(tp_batch_t b, const tp_kargs_t& a, int64_t count, bool timed) {
         tp_kargs_t sub = a;
         sub.w_first = a.w_first + w0;
         sub.w_count = (count - w0 < b->tiled_capacity) ? (count - w0) : b->tiled_capacity;
-        hipError_t e = tp_tiled_launch(sub, ws, h->stream);
+        hipError_t e = tp_tiled_launch(sub, ws, h->stream, w0 == 0);     // the shared sums once per run, not per sub-batch
         if (e != hipSuccess) return fail(h, TP_ERR_HIP, "tiled pipeline launch failed: %s", hipGetErrorString(e));
     }
     h->last_launch = tp_launch_info_t{(int)(count < b->tiled_capacity ? count : b->tiled_capacity), 256, 36864, ws.NS * 4};
@@ -494,11 +494,14 @@ static int plan_shared_gram(tp_batch_t b, const tp_inputs_t* in) {
     b->prefix_nblk = 0;
     const tp_params_t& p = b->p;
     if ((p.flags & TP_FLAG_NO_SHARED_GRAM) || getenv("TP_NO_SHARED_GRAM")) return TP_OK;
-    if (p.k > tp_fused_max_assets() || in->row_idx || in->col_idx || in->rf_adj || !in->start) return TP_OK;
+    if (in->row_idx || in->col_idx || in->rf_adj || !in->start) return TP_OK;
     const long long rows = in->ret_num ? in->ret_rows : in->panel_rows;
     int nblk = 0;
-    const size_t bytes = tp_fused_prefix_bytes(p.k, rows, &nblk);
+    const size_t bytes = p.k <= tp_fused_max_assets() ? tp_fused_prefix_bytes(p.k, rows, &nblk)
+                                                      : tp_tiled_prefix_bytes(p.k, rows, &nblk);
     if (nblk < 2 || (double)b->W * p.n_r < 3.0 * (double)rows) return TP_OK;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 3) return TP_OK;   // never crowd out the batch itself
     if ((size_t)in->panel_ld * 8 * 4096 >= (1ull << 32)) return TP_OK;      // 32-bit offsets inside a segment
     int rc = ensure(h, b->prefix, bytes);
     if (rc != TP_OK) return rc;

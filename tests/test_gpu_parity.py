@@ -389,3 +389,31 @@ def test_layouts_are_bitwise_equivalent(native, k, N, hf_days):
         assert np.array_equal(j1, j2)
         j3, _, _ = native.posterior_batch("jeffreys", k, N, 5.0, **jkw)
         np.testing.assert_allclose(j3, j1, rtol=0, atol=1e-11 * max(1.0, np.abs(j1).max()))
+
+
+@pytest.mark.parametrize("k,N,hf_days,strat,W", [(7, 600, 1, "conjugate", 40), (100, 250, 1, "conjugate", 300),
+                                                 (130, 700, 2, "jeffreys", 50), (200, 1200, 3, "conjugate", 20),
+                                                 (240, 300, 2, "conjugate", 40), (300, 700, 1, "jeffreys", 30),
+                                                 (500, 250, 5, "conjugate", 48), (1000, 500, 22, "conjugate", 20)])
+def test_shared_gram_prefixes(native, k, N, hf_days, strat, W):
+    """Rolling windows over one panel (register-tile path and tiled path; windows that span several restarts of the running sums): the whole aligned 16-row blocks of every window come from the
+    shared running sums (W n_r >= 3 panel rows switches them on) - against the oracle at the flat 1e-10 bound, against
+    the same batch with TP_FLAG_NO_SHARED_GRAM to a few ulps, and bit-identical for any sub-batch (the sums depend
+    on the panel only)."""
+    inp = synthetic.make_kernel_inputs(k, N, W, seed=990000 + k, hf_days=hf_days, hf_period=8)
+    kw = dict(panel=inp["panel"], start=inp["start"], n_r=inp["n_r"])
+    if strat == "conjugate":
+        kw.update(hf_panel=inp["hf_panel"], hf_start=inp["hf_start"], m=inp["m"], w0=inp["w0"], n0=inp["n0"])
+    assert W * inp["n_r"] >= 3 * inp["panel"].shape[0]
+    wts, status, aux = native.posterior_batch(strat, k, N, 5.0, **kw)
+    plain, pstat, paux = native.posterior_batch(strat, k, N, 5.0, flags=native.FLAG_NO_SHARED_GRAM, **kw)
+    assert (status == 0).all() and (pstat == 0).all()
+    np.testing.assert_allclose(wts, plain, rtol=0, atol=1e-12 * max(1.0, np.abs(plain).max()))
+    sel = np.array([0, 1, W // 2, W - 1])
+    sub = {key: (val[sel] if key in ("start", "hf_start", "w0", "n0") else val) for key, val in kw.items()}
+    ref, rstat, _ = oracle.posterior_batch_c(strat, k, N, 5.0, **sub)
+    np.testing.assert_allclose(wts[sel], ref, **WTOL)
+    half = {key: (val[W // 3:] if key in ("start", "hf_start", "w0", "n0") else val) for key, val in kw.items()}
+    assert (W - W // 3) * inp["n_r"] >= 3 * inp["panel"].shape[0]
+    wh, _, _ = native.posterior_batch(strat, k, N, 5.0, **half)
+    assert np.array_equal(wh, wts[W // 3:])
