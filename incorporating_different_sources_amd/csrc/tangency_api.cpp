@@ -283,7 +283,13 @@ int ensure_tiled_ws(tp_batch_t b, tp_tiled_ws_t* ws) {
     int KP, NS, NSB;
     tp_tiled_geometry(b->p.k, &KP, &NS, &NSB);
     const size_t per_window = sizeof(double) * ((size_t)KP * KP + (size_t)NSB * 64 * 64 + KP + (size_t)b->p.m + 8) + 4;
-    int64_t G = (int64_t)((6ULL << 30) / per_window);
+    // in-flight windows of one sub-batch: an arena budget of 32 GiB of the 288 (fewer, larger launches: measured
+    // +2-4 % over 6 GiB at k = 500), never more than a third of what is free; TP_TILED_ARENA_GIB overrides it
+    unsigned long long gib = 32;
+    { size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (free_b >> 30) / 3 < gib) gib = (free_b >> 30) / 3 > 1 ? (free_b >> 30) / 3 : 1; }
+    if (const char* e = getenv("TP_TILED_ARENA_GIB")) { const long v = atol(e); if (v >= 1 && v <= 200) gib = (unsigned long long)v; }
+    int64_t G = (int64_t)((gib << 30) / per_window);
     if (G < 1) G = 1;
     if (G > b->W) G = b->W;
     if (G > 65535) G = 65535;
