@@ -241,6 +241,8 @@ struct RowSource {
     const double* sub_row;  // per-row subtrahend (rf_adj) or nullptr
     int count;              // rows of this window
     bool off32;             // every byte offset from `base` (explicit rows) / from the window's first row fits 32 bits
+    int count0 = 0x7fffffff; // lean daily path: staged rows r >= count0 are panel rows first + r + jump (a second row range)
+    int jump = 0;
 };
 
 // ---- staging.  VALU instructions are the scarce resource of this kernel: on gfx950 a wavefront streaming
@@ -427,7 +429,12 @@ __device__ __forceinline__ void gram_phase_lean(const RowSource& src, int k, dou
     auto load = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int ps = 0; ps < C::PASSES; ++ps) {
-            const unsigned o = voff < vmax ? voff : vmax;                          // rows past the end re-read the last row
+            unsigned o = voff < vmax ? voff : vmax;                                // rows past the end re-read the last row
+            if constexpr (!HF) {                                                   // two row ranges: from the row number
+                const int r = row + ps * C::ROWS_PER_PASS;
+                const int rc = r < src.count ? r : src.count - 1;
+                o = __umul24((unsigned)(rc + (rc >= src.count0 ? src.jump : 0)), ld8) + 8u * (unsigned)cb;
+            }
             sub[ps] = 0.0;
             if (has_sub) { const int r = row + ps * C::ROWS_PER_PASS; sub[ps] = src.sub_row[r < src.count ? r : src.count - 1]; }
 #pragma unroll
@@ -794,15 +801,13 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
             constexpr int BLK = C::CH;
             const long long b0 = (ds.first + BLK - 1) / BLK, b1 = (ds.first + ds.count) / BLK;
             const bool shared = A.prefix != nullptr && b1 > b0;
-            const int lo_count = shared ? (int)(BLK * b0 - ds.first) : ds.count;
-            const int hi_count = shared ? (int)(ds.first + ds.count - BLK * b1) : 0;
-#pragma nounroll
-            for (int e = 0; e < 2; ++e) {                  // e = 0: the rows in front (or all rows), e = 1: the rows behind
-                RowSource part = ds;
-                part.first = e ? BLK * b1 : ds.first;
-                part.count = e ? hi_count : lo_count;
-                if (part.count > 0) gram_phase_lean<C, false, FIX>(part, k, lds, tid0, wv, acc);
+            RowSource part = ds;
+            if (shared) {              // the rows in front of the first whole block, then the rows behind the last one
+                part.count0 = (int)(BLK * b0 - ds.first);
+                part.jump = (int)(BLK * b1 - ds.first) - part.count0;
+                part.count = part.count0 + (int)(ds.first + ds.count - BLK * b1);
             }
+            if (part.count > 0) gram_phase_lean<C, false, FIX>(part, k, lds, tid0, wv, acc);
             if (shared) {
                 // running sums restart every TP_PREFIX_SEG blocks (bounded cancellation): slot g (SEG+1) + l
                 // holds the sum of blocks [g SEG, g SEG + l) of segment g, l = 0 .. SEG
