@@ -581,8 +581,16 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
     constexpr int kI = NT - 1;                 // tile column of the border column
     const int kc = k - 16 * kI;                // its local column (0..15) = number of real rows/cols in block kI
     const int NTB = (kc == 0) ? NT - 1 : NT;   // block rows that hold pivots
-    const long long w = A.w_first + blockIdx.x;   // one workgroup per window
-    if (w >= A.w_first + A.w_count) return;
+    // One workgroup per window, XCD-aware: MI355X deals consecutive workgroup ids round-robin to its 8 XCDs (each
+    // with an L2 of its own), so id -> (xcd = id % 8, slot = id / 8) -> window xcd * ceil(count / 8) + slot gives
+    // every XCD ONE contiguous range of windows, in order.  Neighbouring rolling windows share their panel rows and -
+    // 16 at a time - the very same slots of the shared Gram prefixes (57 KB each at k = 100): with the plain
+    // id -> window map those 16 windows sat on 8 different XCDs and the prefix reads (2-3 slots per window, the
+    // largest data stream of the kernel since round 2) came from the Infinity Cache instead of L2.
+    const long long per_xcd = (A.w_count + 7) >> 3;
+    const long long wl = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((long long)(blockIdx.x >> 3) >= per_xcd || wl >= A.w_count) return;
+    const long long w = A.w_first + wl;
 
     const int* cols = A.col_idx ? A.col_idx + w * k : nullptr;
     d4 acc[C::SLOTS];
@@ -1275,7 +1283,8 @@ hipError_t launch_variant(const tp_kargs_t& a, int grid, hipStream_t stream, tp_
         attr_done = true;
     }
     if (info) { info->grid = grid; info->block = C::NTHREADS; info->lds_bytes = C::LDS_BYTES; info->ntile = NT; }
-    hipLaunchKernelGGL((posterior_fused_kernel<NT, NW, LEAN>), dim3(grid), dim3(C::NTHREADS), C::LDS_BYTES, stream, a);
+    const int grid8 = 8 * ((grid + 7) / 8);            // whole rounds of the 8 XCDs (window_body maps ids to windows)
+    hipLaunchKernelGGL((posterior_fused_kernel<NT, NW, LEAN>), dim3(grid8), dim3(C::NTHREADS), C::LDS_BYTES, stream, a);
     return hipGetLastError();
 }
 
