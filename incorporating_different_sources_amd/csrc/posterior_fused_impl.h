@@ -834,16 +834,19 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
                     for_tiles<C, WV>([&](auto sc_, auto, auto) __attribute__((always_inline)) {
                         constexpr int s = decltype(sc_)::value;
                         constexpr long long t = s * NW + WV;
-                        const double* pS = A.prefix + slotS * SLOT + t * TILE + lane;
-                        const double* pE = A.prefix + slotE * SLOT + t * TILE + lane;
-                        const double* pT = A.prefix + slotT * SLOT + t * TILE + lane;
+                        // [slot][tile][2][64 lanes][2]: registers (0,1) and (2,3) of a lane are 16 contiguous bytes
+                        typedef double d2 __attribute__((ext_vector_type(2)));
+                        const d2* pS = (const d2*)(A.prefix + slotS * SLOT + t * TILE) + lane;
+                        const d2* pE = (const d2*)(A.prefix + slotE * SLOT + t * TILE) + lane;
+                        const d2* pT = (const d2*)(A.prefix + slotT * SLOT + t * TILE) + lane;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            double mid = pE[64 * r];
-                            for (int q = nmid; q >= 1; --q) mid += pT[64 * r + q * tstride];   // whole segments in between,
-                            if (span) mid += pT[64 * r] - pS[64 * r];                          // the last one first
-                            else mid -= pS[64 * r];
-                            acc[s][r] += mid;
+                        for (int h = 0; h < 2; ++h) {
+                            d2 mid = pE[64 * h];
+                            for (int q = nmid; q >= 1; --q) mid += pT[64 * h + q * (tstride / 2)];   // whole segments in between,
+                            if (span) mid += pT[64 * h] - pS[64 * h];                              // the last one first
+                            else mid -= pS[64 * h];
+                            acc[s][2 * h] += mid[0];
+                            acc[s][2 * h + 1] += mid[1];
                         }
                     });
                 });
@@ -1227,8 +1230,8 @@ __global__ void __launch_bounds__(64 * NW, tp_min_waves_for_tiles(NT)) posterior
 // Running Gram sums of the daily panel over aligned blocks of C::CH rows, restarted every TP_PREFIX_SEG blocks: one
 // workgroup per segment walks its blocks with the staging and MFMA loop of the window kernel (same tile ownership,
 // same accumulator layout) and stores the accumulators BEFORE each block - slot l of segment g = sum of the
-// blocks [g SEG, g SEG + l) - and once more after the last one.  Layout [slot][tile][4][64] doubles: a window's wave
-// loads its tiles' registers with coalesced 512-byte reads.  Column k of every block is the ones column, so the
+// blocks [g SEG, g SEG + l) - and once more after the last one.  Layout [slot][tile][2][64 lanes][2] doubles: a window's
+// wave loads the four registers of a tile with two coalesced 16-byte-per-lane reads.  Column k of every block is the ones column, so the
 // border column of the sums is t = X'1 and the corner the row count, exactly as in phase D.
 template <int NT, int NW>
 __global__ void __launch_bounds__(64 * NW) prefix_gram_kernel(const tp_kargs_t A, double* __restrict__ out, const int nblk) {
@@ -1255,9 +1258,10 @@ __global__ void __launch_bounds__(64 * NW) prefix_gram_kernel(const tp_kargs_t A
             for_tiles<C, WV>([&](auto sc_, auto, auto) __attribute__((always_inline)) {
                 constexpr int s = decltype(sc_)::value;
                 constexpr long long t = s * NW + WV;
-                double* p = seg + l * SLOT + t * TILE + lane;
+                typedef double d2 __attribute__((ext_vector_type(2)));
+                d2* p = (d2*)(seg + l * SLOT + t * TILE) + lane;       // 16-byte stores: half the store instructions
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p[64 * r] = acc[s][r];
+                for (int h = 0; h < 2; ++h) p[64 * h] = d2{acc[s][2 * h], acc[s][2 * h + 1]};
             });
         });
     };

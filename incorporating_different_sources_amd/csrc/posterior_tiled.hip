@@ -497,16 +497,22 @@ __device__ __forceinline__ void gram64_lean_body(const tp_kargs_t& A, const tp_t
         const double* pT = A.prefix + (slotT * ntile + tile) * (SB * SB) + wv * 1024 + lane;
         const long long tstride = (SEG + 1) * ntile * (SB * SB);      // from one segment's total to the next one's
         const int nmid = span ? (int)(gE - gS - 1) : 0;               // whole segments between the first and the last
+        // [..][wave][16-column group b][2][64 lanes][2]: registers (0,1) and (2,3) of a lane are 16 contiguous bytes
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const d2* qS = (const d2*)(pS - lane) + lane;
+        const d2* qE = (const d2*)(pE - lane) + lane;
+        const d2* qT = (const d2*)(pT - lane) + lane;
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = (b * 4 + r) * 64;
-                double mid = pE[o];
-                for (int q = nmid; q >= 1; --q) mid += pT[o + q * tstride];      // fixed order: last whole segment first
-                if (span) mid += pT[o] - pS[o];
-                else mid -= pS[o];
-                acc[b][r] += mid;
+            for (int h = 0; h < 2; ++h) {
+                const int o = (b * 2 + h) * 64;
+                d2 mid = qE[o];
+                for (int q = nmid; q >= 1; --q) mid += qT[o + q * (tstride / 2)];      // fixed order: last whole segment first
+                if (span) mid += qT[o] - qS[o];
+                else mid -= qS[o];
+                acc[b][2 * h] += mid[0];
+                acc[b][2 * h + 1] += mid[1];
             }
     }
 #pragma unroll
@@ -519,7 +525,7 @@ __device__ __forceinline__ void gram64_lean_body(const tp_kargs_t& A, const tp_t
 // Running Gram sums of the daily panel for the tiled path: one workgroup per (segment of TP_PREFIX_SEG blocks of CH
 // rows, 64 x 64 super-tile); it walks the segment's blocks like the daily half of the Gram kernel (ones in the border
 // column, zeros beyond) and stores its accumulators before every block and once after the last: slot l of segment
-// g = sum of blocks [g SEG, g SEG + l).  Layout [slot][super-tile pair][wave][16-column group][4][64].
+// g = sum of blocks [g SEG, g SEG + l).  Layout [slot][super-tile pair][wave][16-column group][2][64 lanes][2].
 template <bool EDGE>
 __device__ __forceinline__ void prefix64_body(const tp_kargs_t& A, const tp_tiled_ws_t& ws, double* lds, double* out,
                                               const long long g, const int nb, const long long tile, const int SI, const int SJ) {
@@ -546,11 +552,12 @@ __device__ __forceinline__ void prefix64_body(const tp_kargs_t& A, const tp_tile
     const long long ntile = (long long)ws.NS * (ws.NS + 1) / 2;
     double* seg = out + (g * (SEG + 1) * ntile + tile) * (SB * SB) + wv * 1024 + lane;
     auto store_slot = [&](int l) __attribute__((always_inline)) {
-        double* p = seg + (long long)l * ntile * (SB * SB);
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2* p = (d2*)(seg - lane + (long long)l * ntile * (SB * SB)) + lane;     // 16-byte stores
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p[(b * 4 + r) * 64] = acc[b][r];
+            for (int h = 0; h < 2; ++h) p[(b * 2 + h) * 64] = d2{acc[b][2 * h], acc[b][2 * h + 1]};
     };
     double v[8];
     auto load = [&](int ch) __attribute__((always_inline)) {
