@@ -46,8 +46,8 @@ def alg_flops_per_window(k, n_r, m, conj=True):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=0,
                     help="BASELINE.json config id (default: 2 = k100/n250/10k windows at N=1, 4 = its 8-GPU form at N>1)")
     ap.add_argument("--windows", type=int, default=0, help="override windows per GPU")
@@ -173,6 +173,7 @@ def worker(args):
         kw.update(hf_panel=inp["hf_panel"], hf_start=inp["hf_start"], w0=inp["w0"], n0=inp["n0"])
     batch.upload(**kw)
     h2d_ms = dev.last_timing()["h2d_ms"]
+    shared_blocks = batch.shared_gram_blocks()
 
     def step():
         batch.run()
@@ -296,12 +297,14 @@ def worker(args):
                                    + (f" (m={m} intraday returns, VIX-style n0)" if conj else ""),
                        "k": k, "N": N, "n_r": n_r, "m": m if conj else 0, "windows_per_gpu": W,
                        "strategy": args.strategy, "parallelism": f"windows sharded x{cp.world}",
+                       "shared_gram_row_blocks": shared_blocks,
                        "gather": gather_mode, "rccl_ranks": rccl_ranks, "gather_verified": gathered_ok,
                        "rehearsal": rehearsal, "seed": shp["seed"]},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes)" if traffic else None,
-                         "kernel": "posterior_fused_kernel" if k <= 239 else "tiled pipeline (tile64_kernel<GRAM/TRSM/SYRK> + diag + solve)",
+                         "kernel": ("posterior_fused_kernel" + (" (+ prefix_gram_kernel in front of it, every step)" if shared_blocks else ""))
+                                   if k <= 239 else "tiled pipeline (prior + prefix + gram + diag / TRSM / SYRK + solve)",
                          "kernel_ms": kernel_ms,
                          "alg_flops_per_window": alg_flops_per_window(k, n_r, m, conj),
                          "alg_bytes_per_window": alg_bytes_per_window(k, n_r, m, conj)},

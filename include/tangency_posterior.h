@@ -148,6 +148,9 @@ int tp_batch_upload(tp_batch_t b, const tp_inputs_t* in);   /* H2D, synchronous 
  * of this batch waits for the copies on the device.  Validation of the index arrays still happens in the call. */
 int tp_batch_upload_async(tp_batch_t b, const tp_inputs_t* in);
 int tp_batch_upload_wait(tp_batch_t b);                     /* host wait for the queued copies; sets h2d_ms */
+/* After an upload: the number of aligned row blocks of the daily panel whose Gram sums the windows of this batch share
+ * (rolling windows in the contiguous layout); 0 when every window sums all its own rows. */
+int tp_batch_shared_gram_blocks(tp_batch_t b);
 /* Page-locked host memory for panels and result arrays (hipHostMalloc): DMA at PCIe rate, asynchronous. */
 int tp_host_alloc(void** out, int64_t bytes);
 int tp_host_free(void* p);

@@ -642,6 +642,8 @@ int tp_host_free(void* p) {
     return hipHostFree(p) == hipSuccess ? TP_OK : TP_ERR_HIP;
 }
 
+int tp_batch_shared_gram_blocks(tp_batch_t b) { return b ? b->prefix_nblk : 0; }
+
 int tp_batch_set_rhs(tp_batch_t b, const double* rhs) {
     if (!b) return TP_ERR_INVALID;
     tp_handle_t h = b->h;

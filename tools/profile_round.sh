@@ -11,13 +11,13 @@ cd "$ROOT"
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 python3 bench.py --strategy jeffreys --no-cpu-baseline --no-end-to-end > "$OUT/bench_c2j.json" 2>> "$OUT/bench.err"
 python3 bench.py --config 1 --no-cpu-baseline --no-end-to-end > "$OUT/bench_c1.json" 2>> "$OUT/bench.err"
-python3 bench.py --config 3 --windows 4096 --steps 5 --warmup 1 > "$OUT/bench_c3.json" 2>> "$OUT/bench.err"
-python3 bench.py --config 5 --windows 384 --steps 3 --warmup 1 > "$OUT/bench_c5.json" 2>> "$OUT/bench.err"
+python3 bench.py --config 3 --windows 4096 --steps 5 --warmup 1 --no-end-to-end > "$OUT/bench_c3.json" 2>> "$OUT/bench.err"
+python3 bench.py --config 5 --windows 384 --steps 3 --warmup 1 --no-end-to-end > "$OUT/bench_c5.json" 2>> "$OUT/bench.err"
 python3 bench.py --rehearse-gather --no-cpu-baseline --no-end-to-end > "$OUT/bench_rehearse_gather.json" 2>> "$OUT/bench.err"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-end-to-end > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof.err"
-rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats_c3" -- python3 "$ROOT/bench.py" --config 3 --windows 4096 --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>> "$OUT/rocprof.err"
-rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats_c5" -- python3 "$ROOT/bench.py" --config 5 --windows 384 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>> "$OUT/rocprof.err"
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-end-to-end > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof.err"
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats_c3" -- python3 "$ROOT/bench.py" --config 3 --windows 4096 --steps 5 --warmup 1 --no-end-to-end --no-cpu-baseline > /dev/null 2>> "$OUT/rocprof.err"
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats_c5" -- python3 "$ROOT/bench.py" --config 5 --windows 384 --steps 3 --warmup 1 --no-end-to-end --no-cpu-baseline > /dev/null 2>> "$OUT/rocprof.err"
 rocprofv3 --pmc FETCH_SIZE -f csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2>> "$OUT/rocprof.err"
 rocprofv3 --pmc WRITE_SIZE -f csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > /dev/null 2>> "$OUT/rocprof.err"
 find "$OUT" -name "*_agent_info.csv" -delete
