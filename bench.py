@@ -303,7 +303,7 @@ def worker(args):
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes)" if traffic else None,
-                         "kernel": ("posterior_fused_kernel" + (" (+ prefix_gram_kernel in front of it, every step)" if shared_blocks else ""))
+                         "kernel": ("posterior_fused_kernel" + (" (+ block_gram_kernel and tp_window_sums_kernel in front of it, every step)" if shared_blocks else ""))
                                    if k <= 239 else "tiled pipeline (prior + prefix + gram + diag / TRSM / SYRK + solve)",
                          "kernel_ms": kernel_ms,
                          "alg_flops_per_window": alg_flops_per_window(k, n_r, m, conj),

@@ -20,3 +20,40 @@ hipError_t tp_fused_launch(const tp_kargs_t& a, int grid, hipStream_t stream, tp
         default: return hipErrorInvalidValue;
     }
 }
+
+// Block-window sums of the shared daily Gram: Q_L[b0] = G[b0] + ... + G[b0 + L - 1] for every block position b0 and each
+// block count L the batch needs.  Elementwise (16 bytes per thread): a thread owns one pair of doubles for a run of
+// TP_WINSUM_RUN consecutive positions - the first sum of the run is taken in full (ascending blocks), the following ones
+// slide (add the entering block, subtract the leaving one), so the rounding of Q_L[b0] depends on the panel and on b0
+// alone.  HBM / L2-bound: reads 2 slots and writes 1 per position.
+typedef double tp_d2 __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256) tp_window_sums_kernel(const tp_d2* __restrict__ G, tp_d2* __restrict__ Q, int nblk,
+                                                             long long slot_pairs, int4 Ls, int n_L) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= slot_pairs) return;
+    const int li = blockIdx.z;
+    const int L = li == 0 ? Ls.x : li == 1 ? Ls.y : li == 2 ? Ls.z : Ls.w;
+    const int npos = nblk - L + 1;                          // positions b0 with b0 + L <= nblk
+    const int bs = blockIdx.y * TP_WINSUM_RUN;
+    if (li >= n_L || L < 1 || bs >= npos) return;
+    const int be = bs + TP_WINSUM_RUN < npos ? bs + TP_WINSUM_RUN : npos;
+    tp_d2 sum = G[(long long)bs * slot_pairs + e];
+    for (int b = bs + 1; b < bs + L; ++b) sum += G[(long long)b * slot_pairs + e];
+    tp_d2* out = Q + (long long)li * nblk * slot_pairs;
+    out[(long long)bs * slot_pairs + e] = sum;
+    for (int b0 = bs + 1; b0 < be; ++b0) {
+        sum += G[(long long)(b0 + L - 1) * slot_pairs + e] - G[(long long)(b0 - 1) * slot_pairs + e];
+        out[(long long)b0 * slot_pairs + e] = sum;
+    }
+}
+
+hipError_t tp_window_sums_launch(const double* G, double* Q, int nblk, size_t slot_doubles, const int* L, int n_L,
+                                 hipStream_t stream) {
+    if (n_L < 1 || nblk < 1) return hipSuccess;
+    const long long slot_pairs = (long long)(slot_doubles / 2);
+    const int runs = (nblk + TP_WINSUM_RUN - 1) / TP_WINSUM_RUN;
+    const int4 Ls = make_int4(L[0], n_L > 1 ? L[1] : 0, n_L > 2 ? L[2] : 0, n_L > 3 ? L[3] : 0);
+    hipLaunchKernelGGL(tp_window_sums_kernel, dim3((unsigned)((slot_pairs + 255) / 256), (unsigned)runs, (unsigned)n_L), dim3(256), 0,
+                       stream, (const tp_d2*)G, (tp_d2*)Q, nblk, slot_pairs, Ls, n_L);
+    return hipGetLastError();
+}

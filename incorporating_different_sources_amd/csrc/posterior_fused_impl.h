@@ -800,15 +800,18 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
         ds.count = A.n_rows ? A.n_rows[w] : A.n_r;
         ds.off32 = (A.panel_off32 & (ds.ridx ? 1 : 2)) != 0;
         if constexpr (LEAN) {
-            // Shared Gram prefixes (tp_kargs_t.prefix, prefix_gram_kernel below): the rows of this window that form
-            // whole aligned C::CH-row blocks of the panel come as the difference of two running sums that EVERY
-            // window over the panel shares; only the < C::CH rows in front of the first whole block and behind the
-            // last one go through the MFMAs here.  Rolling windows overlap almost entirely (stride 1: 248 of 249
-            // rows), so the daily Gram of a window costs ~5 k-steps instead of 63.  The decomposition depends on the
-            // window's panel rows only - never on which other windows are in the batch.
+            // Shared Gram sums (block_gram_kernel below + tp_window_sums_kernel): the rows of this window that form whole
+            // aligned C::CH-row blocks of the panel come as ONE precomputed block-window sum Q_L[b0] that every window
+            // with the same blocks shares; only the < C::CH rows in front of the first whole block and behind the last
+            // one go through the MFMAs here.  Rolling windows overlap almost entirely (stride 1: 248 of 249 rows), so
+            // the daily Gram of a window costs ~3 k-steps instead of 63.  The decomposition depends on the window's
+            // panel rows only - never on which other windows are in the batch.
             constexpr int BLK = C::CH;
             const long long b0 = (ds.first + BLK - 1) / BLK, b1 = (ds.first + ds.count) / BLK;
-            const bool shared = A.prefix != nullptr && b1 > b0;
+            // which of the batch's block-window tables holds this window's block count (the host planned them)
+            const int Lw = (int)(b1 - b0);
+            const int li = Lw == A.winsum_L[0] ? 0 : Lw == A.winsum_L[1] ? 1 : Lw == A.winsum_L[2] ? 2 : Lw == A.winsum_L[3] ? 3 : -1;
+            const bool shared = A.winsum != nullptr && Lw > 0 && li >= 0;
             RowSource part = ds;
             if (shared) {              // the rows in front of the first whole block, then the rows behind the last one
                 part.count0 = (int)(BLK * b0 - ds.first);
@@ -817,18 +820,10 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
             }
             if (part.count > 0) gram_phase_lean<C, false, FIX>(part, k, lds, tid0, wv, acc);
             if (shared) {
-                // running sums restart every TP_PREFIX_SEG blocks (bounded cancellation): slot g (SEG+1) + l
-                // holds the sum of blocks [g SEG, g SEG + l) of segment g, l = 0 .. SEG
-                constexpr int SEG = TP_PREFIX_SEG;
-                const long long gS = b0 / SEG, gE = (b1 - 1) / SEG;
-                const long long slotS = gS * (SEG + 1) + (b0 - gS * SEG);
-                const long long slotE = gE * (SEG + 1) + (b1 - gE * SEG);
-                const long long slotT = gS * (SEG + 1) + SEG;                  // whole first segment (gE = gS + 1)
-                const bool span = gE != gS;
-                const int nmid = span ? (int)(gE - gS - 1) : 0;                // whole segments between the two ends
+                // ONE table slot: Q_L[b0] = the Gram of the window's L whole blocks (window_sums kernel)
                 TP_LANE_CONSTANTS();
                 constexpr long long TILE = 4 * 64, SLOT = (long long)C::NTILES * TILE;
-                constexpr long long tstride = (SEG + 1) * SLOT;                // from one segment's total to the next one's
+                const double* q = A.winsum + ((long long)li * A.prefix_nblk + b0) * SLOT;
                 wave_sel<NW, FIX>(wv, [&](auto wc) __attribute__((always_inline)) {
                     constexpr int WV = decltype(wc)::value;
                     for_tiles<C, WV>([&](auto sc_, auto, auto) __attribute__((always_inline)) {
@@ -836,17 +831,12 @@ __device__ __forceinline__ void window_body(const tp_kargs_t& A, double* lds, co
                         constexpr long long t = s * NW + WV;
                         // [slot][tile][2][64 lanes][2]: registers (0,1) and (2,3) of a lane are 16 contiguous bytes
                         typedef double d2 __attribute__((ext_vector_type(2)));
-                        const d2* pS = (const d2*)(A.prefix + slotS * SLOT + t * TILE) + lane;
-                        const d2* pE = (const d2*)(A.prefix + slotE * SLOT + t * TILE) + lane;
-                        const d2* pT = (const d2*)(A.prefix + slotT * SLOT + t * TILE) + lane;
+                        const d2* pq = (const d2*)(q + t * TILE) + lane;
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            d2 mid = pE[64 * h];
-                            for (int q = nmid; q >= 1; --q) mid += pT[64 * h + q * (tstride / 2)];   // whole segments in between,
-                            if (span) mid += pT[64 * h] - pS[64 * h];                              // the last one first
-                            else mid -= pS[64 * h];
-                            acc[s][2 * h] += mid[0];
-                            acc[s][2 * h + 1] += mid[1];
+                            const d2 v2 = pq[64 * h];
+                            acc[s][2 * h] += v2[0];
+                            acc[s][2 * h + 1] += v2[1];
                         }
                     });
                 });
@@ -1227,46 +1217,37 @@ __global__ void __launch_bounds__(64 * NW, tp_min_waves_for_tiles(NT)) posterior
 #endif
 }
 
-// Running Gram sums of the daily panel over aligned blocks of C::CH rows, restarted every TP_PREFIX_SEG blocks: one
-// workgroup per segment walks its blocks with the staging and MFMA loop of the window kernel (same tile ownership,
-// same accumulator layout) and stores the accumulators BEFORE each block - slot l of segment g = sum of the
-// blocks [g SEG, g SEG + l) - and once more after the last one.  Layout [slot][tile][2][64 lanes][2] doubles: a window's
-// wave loads the four registers of a tile with two coalesced 16-byte-per-lane reads.  Column k of every block is the ones column, so the
-// border column of the sums is t = X'1 and the corner the row count, exactly as in phase D.
+// Grams of the aligned C::CH-row blocks of the daily panel, one workgroup per block, with the staging and MFMA loop of
+// the window kernel (same tile ownership, same accumulator layout).  Layout [block][tile][2][64 lanes][2] doubles: a
+// window's wave loads the four registers of a tile with two coalesced 16-byte-per-lane reads.  Column k of every block
+// is the ones column, so the border column of a block sum is t = X'1 and the corner the row count, as in phase D.
+// tp_window_sums_launch then adds them up to the block-window sums Q_L the windows read.
 template <int NT, int NW>
-__global__ void __launch_bounds__(64 * NW) prefix_gram_kernel(const tp_kargs_t A, double* __restrict__ out, const int nblk) {
+__global__ void __launch_bounds__(64 * NW) block_gram_kernel(const tp_kargs_t A, double* __restrict__ out) {
     using C = Cfg<NT, NW>;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid0 = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-    constexpr int SEG = TP_PREFIX_SEG, BLK = C::CH;
-    const long long g = blockIdx.x;
-    const long long bfirst = g * SEG;
-    const int nb = (int)((nblk - bfirst < SEG) ? (nblk - bfirst) : SEG);
-    if (nb <= 0) return;
     d4 acc[C::SLOTS];
     static_for<0, C::SLOTS>([&](auto sc_) __attribute__((always_inline)) { acc[decltype(sc_)::value] = d4{0.0, 0.0, 0.0, 0.0}; });
     RowSource ds;
-    ds.base = A.panel; ds.ld = A.panel_ld; ds.ridx = nullptr; ds.first = bfirst * BLK; ds.sub_row = nullptr;
-    ds.count = nb * BLK; ds.off32 = true;
+    ds.base = A.panel; ds.ld = A.panel_ld; ds.ridx = nullptr; ds.first = (long long)blockIdx.x * C::CH; ds.sub_row = nullptr;
+    ds.count = C::CH; ds.off32 = true;
+    gram_phase_lean<C, false, -1>(ds, A.k, lds, tid0, wv, acc);
     constexpr long long TILE = 4 * 64, SLOT = (long long)C::NTILES * TILE;
-    double* seg = out + g * (SEG + 1) * SLOT;
-    auto store_slot = [&](int l) __attribute__((always_inline)) {
-        const int lane = fresh(tid0) & 63;
-        wave_dispatch<NW>(wv, [&](auto wc) __attribute__((always_inline)) {
-            constexpr int WV = decltype(wc)::value;
-            for_tiles<C, WV>([&](auto sc_, auto, auto) __attribute__((always_inline)) {
-                constexpr int s = decltype(sc_)::value;
-                constexpr long long t = s * NW + WV;
-                typedef double d2 __attribute__((ext_vector_type(2)));
-                d2* p = (d2*)(seg + l * SLOT + t * TILE) + lane;       // 16-byte stores: half the store instructions
+    double* slot = out + (long long)blockIdx.x * SLOT;
+    const int lane = fresh(tid0) & 63;
+    wave_dispatch<NW>(wv, [&](auto wc) __attribute__((always_inline)) {
+        constexpr int WV = decltype(wc)::value;
+        for_tiles<C, WV>([&](auto sc_, auto, auto) __attribute__((always_inline)) {
+            constexpr int s = decltype(sc_)::value;
+            constexpr long long t = s * NW + WV;
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            d2* p = (d2*)(slot + t * TILE) + lane;               // 16-byte stores
 #pragma unroll
-                for (int h = 0; h < 2; ++h) p[64 * h] = d2{acc[s][2 * h], acc[s][2 * h + 1]};
-            });
+            for (int h = 0; h < 2; ++h) p[64 * h] = d2{acc[s][2 * h], acc[s][2 * h + 1]};
         });
-    };
-    gram_phase_lean<C, false, -1>(ds, A.k, lds, tid0, wv, acc, store_slot);
-    store_slot(nb);
+    });
 }
 
 // the contiguous layout the LEAN kernel is built for: no index arrays, window-relative 32-bit offsets
@@ -1297,19 +1278,22 @@ hipError_t launch_one(const tp_kargs_t& a, int grid, hipStream_t stream, tp_laun
     using C = Cfg<NT, NW>;
     static_assert(C::CH == TP_PREFIX_BLOCK_ROWS(NT), "posterior_kernels.h: block rows of the shared Gram prefixes");
     if (!tp_layout_is_lean(a)) return launch_variant<NT, NW, false>(a, grid, stream, info);
-    if (a.prefix != nullptr) {
-        // the shared running sums first, on the same stream: part of every run, nothing is kept between runs
+    if (a.winsum != nullptr) {
+        // the shared sums first, on the same stream: part of every run, nothing is kept between runs
         static bool attr_done = false;
         if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute((const void*)prefix_gram_kernel<NT, NW>,
+            hipError_t e = hipFuncSetAttribute((const void*)block_gram_kernel<NT, NW>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
             if (e != hipSuccess) return e;
             attr_done = true;
         }
-        const int nseg = (a.prefix_nblk + TP_PREFIX_SEG - 1) / TP_PREFIX_SEG;
-        hipLaunchKernelGGL((prefix_gram_kernel<NT, NW>), dim3(nseg), dim3(C::NTHREADS), C::LDS_BYTES, stream, a,
-                           (double*)a.prefix, a.prefix_nblk);
+        hipLaunchKernelGGL((block_gram_kernel<NT, NW>), dim3((unsigned)a.prefix_nblk), dim3(C::NTHREADS), C::LDS_BYTES, stream, a,
+                           (double*)a.prefix);
         hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        int n_L = 0;
+        while (n_L < TP_WINSUM_MAX_L && a.winsum_L[n_L] > 0) ++n_L;
+        e = tp_window_sums_launch(a.prefix, (double*)a.winsum, a.prefix_nblk, (size_t)C::NTILES * 256, a.winsum_L, n_L, stream);
         if (e != hipSuccess) return e;
     }
     return launch_variant<NT, NW, true>(a, grid, stream, info);

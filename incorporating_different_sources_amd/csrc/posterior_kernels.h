@@ -26,6 +26,10 @@ struct tp_kargs_t {
                           // daily panel, [nseg (TP_PREFIX_SEG + 1)][tiles][4][64] doubles (posterior_fused_impl.h);
                           // filled by every launch before the window kernel reads it
     int prefix_nblk;      // whole TP_PREFIX_BLOCK_ROWS-row blocks of the panel
+    // register-tile path: the workspace holds the per-block Grams G[nblk] and, behind them, one table of block-window
+    // sums Q_L[b0] = G[b0] + .. + G[b0 + L - 1] per block count L that occurs in the batch (at most TP_WINSUM_MAX_L)
+    const double* winsum; // Q tables: [n_L][prefix_nblk][tiles][2][64][2]
+    int winsum_L[4];      // the block counts L (0 = unused entry)
     const double* rhs;    // optional [W x k]: replaces the border column before the factorisation
     const double* shift;  // optional [W x 2], Jeffreys only: (d, e) adds d I + e 1 1' to the matrix that is factorised
     double* weights;
@@ -49,15 +53,21 @@ struct tp_launch_info_t { int grid, block, lds_bytes, ntile; };
 
 // Shared Gram prefixes of the register-tile path: aligned blocks of the staged chunk's rows (16; 32 with eight waves,
 // NT >= 13), running sums restarted every TP_PREFIX_SEG blocks.
-#define TP_PREFIX_SEG 16
+#define TP_PREFIX_SEG 16            /* tiled path: blocks per restart of the running sums */
+#define TP_WINSUM_MAX_L 4           /* register-tile path: distinct whole-block counts per batch that get a table */
+#define TP_WINSUM_RUN 16            /* sliding sums restart every so many block positions */
 #define TP_PREFIX_BLOCK_ROWS(nt) ((nt) <= 12 ? 16 : 32)
-inline size_t tp_fused_prefix_bytes(int k, long long panel_rows, int* nblk_out) {
+// doubles per table slot (one Gram of one block or block window: every upper-triangle tile, 4 registers x 64 lanes)
+inline size_t tp_fused_slot_doubles(int k) { const int nt = (k + 1 + 15) / 16; return (size_t)(nt * (nt + 1) / 2) * 256; }
+inline size_t tp_fused_prefix_bytes(int k, long long panel_rows, int n_L, int* nblk_out) {
     const int nt = (k + 1 + 15) / 16;
     const long long nblk = panel_rows / TP_PREFIX_BLOCK_ROWS(nt);
-    const long long nseg = (nblk + TP_PREFIX_SEG - 1) / TP_PREFIX_SEG;
     if (nblk_out) *nblk_out = (int)nblk;
-    return sizeof(double) * (size_t)(nseg * (TP_PREFIX_SEG + 1)) * (size_t)(nt * (nt + 1) / 2) * 256;
+    return sizeof(double) * (size_t)nblk * (size_t)(1 + n_L) * tp_fused_slot_doubles(k);
 }
+// Q_L tables from the block Grams (posterior_fused.hip): elementwise sliding sums, restarted every TP_WINSUM_RUN positions
+hipError_t tp_window_sums_launch(const double* G, double* Q, int nblk, size_t slot_doubles, const int* L, int n_L,
+                                 hipStream_t stream);
 
 // register-tile fused kernel (posterior_fused.hip): k <= tp_fused_max_assets()
 int tp_fused_max_assets(void);

@@ -62,6 +62,7 @@ struct tp_batch_s {
     DevBuf fe_prices, fe_num, fe_den, fe_hf_prices, fe_hf_num, fe_hf_den;   // price front-end staging (freed after a synchronous upload)
     DevBuf prefix;                                            // shared Gram prefixes of the daily panel (register-tile path)
     int prefix_nblk = 0;                                      // > 0: the layout qualifies (decided at upload)
+    int winsum_L[4] = {0, 0, 0, 0};                           // register-tile path: the whole-block counts of the windows
     DevBuf t_arena, t_rinv, t_ybar, t_zc, t_scal, t_flags;   // large-k path workspace
     int64_t tiled_capacity = 0;                               // windows in flight per sub-batch
     bool uploaded = false;
@@ -166,6 +167,12 @@ tp_kargs_t make_kargs(tp_batch_t b) {
     a.n0 = (const double*)b->n0.p;
     a.prefix = b->prefix_nblk > 0 ? (const double*)b->prefix.p : nullptr;
     a.prefix_nblk = b->prefix_nblk;
+    a.winsum = nullptr;
+    for (int i = 0; i < 4; ++i) a.winsum_L[i] = 0;
+    if (b->prefix_nblk > 0 && b->p.k <= tp_fused_max_assets()) {      // block Grams first, the block-window tables behind them
+        a.winsum = (const double*)b->prefix.p + (size_t)b->prefix_nblk * tp_fused_slot_doubles(b->p.k);
+        for (int i = 0; i < 4; ++i) a.winsum_L[i] = b->winsum_L[i];
+    }
     a.rhs = (const double*)b->rhs.p;
     a.shift = (const double*)b->shift.p;
     a.center_rows = (b->p.flags & TP_FLAG_NO_CENTER) ? 2 : (b->p.flags & TP_FLAG_CENTER_BY_ROWS) ? 1 : 0;
@@ -491,7 +498,7 @@ int tp_batch_destroy(tp_batch_t b) {
 
 // Rolling windows over one shared panel overlap almost entirely; the register-tile path then takes the whole aligned
 // row blocks of every window from running Gram sums of the panel that all windows share (posterior_fused_impl.h,
-// prefix_gram_kernel) instead of pushing every row of every window through the MFMAs.  Qualifies: contiguous windows
+// block_gram_kernel + tp_window_sums_kernel; the tiled path: tiled_prefix_kernel) instead of pushing every row of every window through the MFMAs.  Qualifies: contiguous windows
 // (start[]), no column gather, no per-row risk-free adjustment, k in the register-tile range, and windows that
 // together cover the panel at least three times.  The sums are recomputed by EVERY tp_batch_run (nothing is kept
 // between runs); TP_FLAG_NO_SHARED_GRAM switches the scheme off.
@@ -503,8 +510,29 @@ static int plan_shared_gram(tp_batch_t b, const tp_inputs_t* in) {
     if (in->row_idx || in->col_idx || in->rf_adj || !in->start) return TP_OK;
     const long long rows = in->ret_num ? in->ret_rows : in->panel_rows;
     int nblk = 0;
-    const size_t bytes = p.k <= tp_fused_max_assets() ? tp_fused_prefix_bytes(p.k, rows, &nblk)
-                                                      : tp_tiled_prefix_bytes(p.k, rows, &nblk);
+    size_t bytes = 0;
+    for (int i = 0; i < 4; ++i) b->winsum_L[i] = 0;
+    if (p.k <= tp_fused_max_assets()) {
+        // register-tile path: one table of block-window sums per whole-block count that occurs among the windows
+        // (rolling windows of one length have two: 249 rows over 16-row blocks cover 14 or 15 whole blocks)
+        const int blk = TP_PREFIX_BLOCK_ROWS((p.k + 1 + 15) / 16);
+        int n_L = 0;
+        for (int64_t w = 0; w < b->W; ++w) {
+            const long long first = in->start[w], cnt = in->n_rows ? in->n_rows[w] : p.n_r;
+            const long long L = (first + cnt) / blk - (first + blk - 1) / blk;
+            if (L < 1) continue;
+            int i = 0;
+            while (i < n_L && b->winsum_L[i] != (int)L) ++i;
+            if (i == n_L) {
+                if (n_L == TP_WINSUM_MAX_L) { for (int q = 0; q < 4; ++q) b->winsum_L[q] = 0; return TP_OK; }   // irregular windows: no sharing
+                b->winsum_L[n_L++] = (int)L;
+            }
+        }
+        if (n_L == 0) return TP_OK;
+        bytes = tp_fused_prefix_bytes(p.k, rows, n_L, &nblk);
+    } else {
+        bytes = tp_tiled_prefix_bytes(p.k, rows, &nblk);
+    }
     if (nblk < 2 || (double)b->W * p.n_r < 3.0 * (double)rows) return TP_OK;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 3) return TP_OK;   // never crowd out the batch itself
