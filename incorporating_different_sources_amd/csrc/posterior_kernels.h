@@ -22,13 +22,12 @@ struct tp_kargs_t {
     const int* hf_count;
     const double* w0;
     const double* n0;
-    const double* prefix; // optional (contiguous layout, no rf_adj): workspace of the shared running Gram sums of the
-                          // daily panel, [nseg (TP_PREFIX_SEG + 1)][tiles][4][64] doubles (posterior_fused_impl.h);
-                          // filled by every launch before the window kernel reads it
+    const double* prefix; // optional (contiguous layout, no rf_adj): workspace of the shared Gram sums of the daily panel:
+                          // the per-block Grams G[prefix_nblk][slot], filled by every launch before the window kernel
     int prefix_nblk;      // whole TP_PREFIX_BLOCK_ROWS-row blocks of the panel
-    // register-tile path: the workspace holds the per-block Grams G[nblk] and, behind them, one table of block-window
-    // sums Q_L[b0] = G[b0] + .. + G[b0 + L - 1] per block count L that occurs in the batch (at most TP_WINSUM_MAX_L)
-    const double* winsum; // Q tables: [n_L][prefix_nblk][tiles][2][64][2]
+    // behind the block Grams: one table of block-window sums Q_L[b0] = G[b0] + .. + G[b0 + L - 1] per whole-block count
+    // L that occurs among the batch's windows (at most TP_WINSUM_MAX_L)
+    const double* winsum; // Q tables: [n_L][prefix_nblk][slot]
     int winsum_L[4];      // the block counts L (0 = unused entry)
     const double* rhs;    // optional [W x k]: replaces the border column before the factorisation
     const double* shift;  // optional [W x 2], Jeffreys only: (d, e) adds d I + e 1 1' to the matrix that is factorised
@@ -52,8 +51,7 @@ struct tp_kargs_t {
 struct tp_launch_info_t { int grid, block, lds_bytes, ntile; };
 
 // Shared Gram prefixes of the register-tile path: aligned blocks of the staged chunk's rows (16; 32 with eight waves,
-// NT >= 13), running sums restarted every TP_PREFIX_SEG blocks.
-#define TP_PREFIX_SEG 16            /* tiled path: blocks per restart of the running sums */
+// NT >= 13); 16 rows on the tiled path.
 #define TP_WINSUM_MAX_L 4           /* register-tile path: distinct whole-block counts per batch that get a table */
 #define TP_WINSUM_RUN 16            /* sliding sums restart every so many block positions */
 #define TP_PREFIX_BLOCK_ROWS(nt) ((nt) <= 12 ? 16 : 32)
@@ -89,8 +87,9 @@ struct tp_tiled_ws_t {
 int tp_tiled_max_assets(void);
 void tp_tiled_geometry(int k, int* KP, int* NS, int* NSB);
 hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStream_t stream, bool build_prefix);
-// bytes of the shared running Gram sums of the daily panel in the tiled layout (16-row blocks, TP_PREFIX_SEG per segment)
-size_t tp_tiled_prefix_bytes(int k, long long panel_rows, int* nblk_out);
+// bytes of the shared block Grams + n_L block-window tables of the daily panel in the tiled layout (16-row blocks)
+size_t tp_tiled_prefix_bytes(int k, long long panel_rows, int n_L, int* nblk_out);
+size_t tp_tiled_slot_doubles(int k);
 
 // price front-end (returns_frontend.hip): out[i][c] = log(prices[num[i]][c] / prices[den[i]][c]), NaN -> 0
 hipError_t tp_log_return_rows_launch(const double* prices, int ld, const int* num, const int* den, long long n_out,

@@ -407,7 +407,9 @@ __device__ __forceinline__ void gram64_lean_body(const tp_kargs_t& A, const tp_t
     // rows in front of the first whole block (`lo` of them) and behind the last one are staged here.
     const long long dfirst = A.start ? A.start[w] : 0;
     const long long pb0 = (dfirst + CH - 1) / CH, pb1 = (dfirst + nr) / CH;
-    const bool shared = A.prefix != nullptr && !dridx && pb1 > pb0;
+    const int Lw = (int)(pb1 - pb0);         // whole blocks of this window; the host planned a table for its count
+    const int li = Lw == A.winsum_L[0] ? 0 : Lw == A.winsum_L[1] ? 1 : Lw == A.winsum_L[2] ? 2 : Lw == A.winsum_L[3] ? 3 : -1;
+    const bool shared = A.winsum != nullptr && !dridx && Lw > 0 && li >= 0;
     const int lo = shared ? (int)(CH * pb0 - dfirst) : nr;            // staged daily rows r < lo: window rows r
     const int djump = shared ? (int)(CH * pb1 - dfirst) - lo : 0;     //                  r >= lo: window rows r + djump
     const int nrs = shared ? lo + (int)(dfirst + nr - CH * pb1) : nr; // staged daily rows
@@ -483,36 +485,19 @@ __device__ __forceinline__ void gram64_lean_body(const tp_kargs_t& A, const tp_t
         __syncthreads();
     }
     if (shared) {
-        // slot g (SEG+1) + l = sum of blocks [g SEG, g SEG + l) of segment g (running sums restart every SEG blocks)
-        constexpr int SEG = TP_PREFIX_SEG;
-        const long long gS = pb0 / SEG, gE = (pb1 - 1) / SEG;
-        const long long slotS = gS * (SEG + 1) + (pb0 - gS * SEG);
-        const long long slotE = gE * (SEG + 1) + (pb1 - gE * SEG);
-        const long long slotT = gS * (SEG + 1) + SEG;
-        const bool span = gE != gS;
+        // ONE table slot: Q_L[b0] = the Gram of the window's L whole blocks (tp_window_sums_kernel)
         const long long ntile = (long long)ws.NS * (ws.NS + 1) / 2;
         const long long tile = pair_index(SI, SJ, ws.NS);
-        const double* pS = A.prefix + (slotS * ntile + tile) * (SB * SB) + wv * 1024 + lane;
-        const double* pE = A.prefix + (slotE * ntile + tile) * (SB * SB) + wv * 1024 + lane;
-        const double* pT = A.prefix + (slotT * ntile + tile) * (SB * SB) + wv * 1024 + lane;
-        const long long tstride = (SEG + 1) * ntile * (SB * SB);      // from one segment's total to the next one's
-        const int nmid = span ? (int)(gE - gS - 1) : 0;               // whole segments between the first and the last
         // [..][wave][16-column group b][2][64 lanes][2]: registers (0,1) and (2,3) of a lane are 16 contiguous bytes
         typedef double d2 __attribute__((ext_vector_type(2)));
-        const d2* qS = (const d2*)(pS - lane) + lane;
-        const d2* qE = (const d2*)(pE - lane) + lane;
-        const d2* qT = (const d2*)(pT - lane) + lane;
+        const d2* q = (const d2*)(A.winsum + (((long long)li * A.prefix_nblk + pb0) * ntile + tile) * (SB * SB) + wv * 1024) + lane;
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int o = (b * 2 + h) * 64;
-                d2 mid = qE[o];
-                for (int q = nmid; q >= 1; --q) mid += qT[o + q * (tstride / 2)];      // fixed order: last whole segment first
-                if (span) mid += qT[o] - qS[o];
-                else mid -= qS[o];
-                acc[b][2 * h] += mid[0];
-                acc[b][2 * h + 1] += mid[1];
+                const d2 v2 = q[(b * 2 + h) * 64];
+                acc[b][2 * h] += v2[0];
+                acc[b][2 * h + 1] += v2[1];
             }
     }
 #pragma unroll
@@ -522,92 +507,59 @@ __device__ __forceinline__ void gram64_lean_body(const tp_kargs_t& A, const tp_t
             M[(long long)(64 * SI + 16 * wv + fq + 4 * r) * KP + 64 * SJ + 16 * b + fr] = acc[b][r];
 }
 
-// Running Gram sums of the daily panel for the tiled path: one workgroup per (segment of TP_PREFIX_SEG blocks of CH
-// rows, 64 x 64 super-tile); it walks the segment's blocks like the daily half of the Gram kernel (ones in the border
-// column, zeros beyond) and stores its accumulators before every block and once after the last: slot l of segment
-// g = sum of blocks [g SEG, g SEG + l).  Layout [slot][super-tile pair][wave][16-column group][2][64 lanes][2].
+// Grams of the aligned CH-row blocks of the daily panel for the tiled path: one workgroup per (block, 64 x 64
+// super-tile), staged like the daily half of the Gram kernel (ones in the border column, zeros beyond).  Layout
+// [block][super-tile pair][wave][16-column group][2][64 lanes][2]; tp_window_sums_launch adds them up to the block-window
+// sums Q_L the windows read (posterior_fused_impl.h has the register-tile form of the same scheme).
 template <bool EDGE>
-__device__ __forceinline__ void prefix64_body(const tp_kargs_t& A, const tp_tiled_ws_t& ws, double* lds, double* out,
-                                              const long long g, const int nb, const long long tile, const int SI, const int SJ) {
+__device__ __forceinline__ void blockgram64_body(const tp_kargs_t& A, const tp_tiled_ws_t& ws, double* lds, double* out,
+                                                 const long long blk, const long long tile, const int SI, const int SJ) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int k = A.k;
-    constexpr int SEG = TP_PREFIX_SEG;
-    const char* dub = (const char*)(A.panel + g * SEG * CH * (long long)A.panel_ld);
-    const unsigned dld8 = (unsigned)A.panel_ld * 8u;
-    const int srow = tid >> 4, cb = tid & 15;
-    unsigned co[8];
-    bool cval[8], cbord[8];
+    const double* row = A.panel + (blk * CH + (tid >> 4)) * (long long)A.panel_ld;
+    const int cb = tid & 15;
+    double v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int gc = 64 * ((i >> 2) ? SJ : SI) + cb + 16 * (i & 3);
-        cval[i] = !EDGE || gc < k;
-        cbord[i] = EDGE && gc == k;
-        co[i] = 8u * (unsigned)(cval[i] ? gc : k - 1);
+        const bool cval = !EDGE || gc < k;
+        const double x = row[cval ? gc : k - 1];
+        v[i] = cval ? x : ((EDGE && gc == k) ? 1.0 : 0.0);
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lds[(tid >> 4) * LDX + 64 * (i >> 2) + cb + 16 * (i & 3)] = v[i];
+    __syncthreads();
     d4 acc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
-    const long long ntile = (long long)ws.NS * (ws.NS + 1) / 2;
-    double* seg = out + (g * (SEG + 1) * ntile + tile) * (SB * SB) + wv * 1024 + lane;
-    auto store_slot = [&](int l) __attribute__((always_inline)) {
-        typedef double d2 __attribute__((ext_vector_type(2)));
-        d2* p = (d2*)(seg - lane + (long long)l * ntile * (SB * SB)) + lane;     // 16-byte stores
+    const double* lb = lds + fq * LDX + fr;
+#pragma unroll
+    for (int s4 = 0; s4 < CH / 4; ++s4) {
+        const double a = lb[4 * s4 * LDX + 16 * wv];
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) p[(b * 2 + h) * 64] = d2{acc[b][2 * h], acc[b][2 * h + 1]};
-    };
-    double v[8];
-    auto load = [&](int ch) __attribute__((always_inline)) {
-        const unsigned ro = __umul24((unsigned)(ch * CH + srow), dld8);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = *(const double*)(dub + (size_t)(ro + co[i]));
-    };
-    auto store = [&](double* buf) __attribute__((always_inline)) {
-        if (EDGE) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = cval[i] ? v[i] : (cbord[i] ? 1.0 : 0.0);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) buf[srow * LDX + 64 * (i >> 2) + cb + 16 * (i & 3)] = v[i];
-    };
-    load(0); store(lds);
-    __syncthreads();
-    for (int ch = 0; ch < nb; ++ch) {
-        double* cur = lds + (ch & 1) * CH * LDX;
-        double* nxt = lds + ((ch + 1) & 1) * CH * LDX;
-        const bool more = ch + 1 < nb;
-        if (more) load(ch + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        store_slot(ch);
-        const double* lb = cur + fq * LDX + fr;
-#pragma unroll
-        for (int s4 = 0; s4 < CH / 4; ++s4) {
-            const double a = lb[4 * s4 * LDX + 16 * wv];
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, lb[4 * s4 * LDX + 64 + 16 * b], acc[b], 0, 0, 0);
-        }
-        if (more) store(nxt);
-        __syncthreads();
+            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, lb[4 * s4 * LDX + 64 + 16 * b], acc[b], 0, 0, 0);
     }
-    store_slot(nb);
+    const long long ntile = (long long)ws.NS * (ws.NS + 1) / 2;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2* p = (d2*)(out + (blk * ntile + tile) * (SB * SB) + wv * 1024) + lane;     // 16-byte stores
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) p[(b * 2 + h) * 64] = d2{acc[b][2 * h], acc[b][2 * h + 1]};
 }
 
-__global__ void __launch_bounds__(NTHREADS) tiled_prefix_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws, double* out, const int nblk) {
-    __shared__ __attribute__((aligned(16))) double lds[2 * CH * LDX];
+__global__ void __launch_bounds__(NTHREADS) tiled_block_gram_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws, double* out) {
+    __shared__ __attribute__((aligned(16))) double lds[CH * LDX];
     const long long ntile = (long long)ws.NS * (ws.NS + 1) / 2;
-    const long long g = blockIdx.x / ntile;
+    const long long blk = blockIdx.x / ntile;
     const int tile = (int)(blockIdx.x % ntile);
-    const long long bfirst = g * TP_PREFIX_SEG;
-    const int nb = (int)((nblk - bfirst < TP_PREFIX_SEG) ? (nblk - bfirst) : TP_PREFIX_SEG);
-    if (nb <= 0) return;
     int SI, SJ;
     pair_decode(tile, ws.NS, SI, SJ);
-    if (64 * SJ + 63 < A.k) prefix64_body<false>(A, ws, lds, out, g, nb, tile, SI, SJ);
-    else prefix64_body<true>(A, ws, lds, out, g, nb, tile, SI, SJ);
+    if (64 * SJ + 63 < A.k) blockgram64_body<false>(A, ws, lds, out, blk, tile, SI, SJ);
+    else blockgram64_body<true>(A, ws, lds, out, blk, tile, SI, SJ);
 }
 
 __global__ void __launch_bounds__(NTHREADS) tiled_gram_lean_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws) {
@@ -819,13 +771,16 @@ void tp_tiled_geometry(int k, int* KP, int* NS, int* NSB) {
 }
 
 // Whole pipeline for windows [a.w_first, a.w_first + a.w_count) (a.w_count <= ws capacity), on `stream`.
-size_t tp_tiled_prefix_bytes(int k, long long panel_rows, int* nblk_out) {
+size_t tp_tiled_slot_doubles(int k) {
     int KP, NS, NSB;
     tp_tiled_geometry(k, &KP, &NS, &NSB);
+    return (size_t)(NS * (NS + 1) / 2) * SB * SB;
+}
+
+size_t tp_tiled_prefix_bytes(int k, long long panel_rows, int n_L, int* nblk_out) {
     const long long nblk = panel_rows / CH;
-    const long long nseg = (nblk + TP_PREFIX_SEG - 1) / TP_PREFIX_SEG;
     if (nblk_out) *nblk_out = (int)nblk;
-    return sizeof(double) * (size_t)(nseg * (TP_PREFIX_SEG + 1)) * (size_t)(NS * (NS + 1) / 2) * SB * SB;
+    return sizeof(double) * (size_t)nblk * (size_t)(1 + n_L) * tp_tiled_slot_doubles(k);
 }
 
 hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStream_t stream, bool build_prefix) {
@@ -835,10 +790,14 @@ hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStre
     const bool conj = a.strategy == 0;
     // 32-bit offsets for both panels in the layout they come in (explicit rows: bit 0, contiguous: bit 1)?
     const bool lean = (a.panel_off32 & (a.row_idx ? 1 : 2)) && (!conj || (a.hf_off32 & (a.hf_row_idx ? 1 : 2)));
-    if (build_prefix && a.prefix != nullptr && lean) {      // the shared running sums of the daily panel, once per run
-        const int nseg = (a.prefix_nblk + TP_PREFIX_SEG - 1) / TP_PREFIX_SEG;
-        hipLaunchKernelGGL(tiled_prefix_kernel, dim3((unsigned)(nseg * (NS * (NS + 1) / 2))), dim3(NTHREADS), 0, stream, a, ws,
-                           (double*)a.prefix, a.prefix_nblk);
+    if (build_prefix && a.winsum != nullptr && lean) {      // the shared block Grams and block-window sums, once per run
+        hipLaunchKernelGGL(tiled_block_gram_kernel, dim3((unsigned)((long long)a.prefix_nblk * (NS * (NS + 1) / 2))), dim3(NTHREADS), 0,
+                           stream, a, ws, (double*)a.prefix);
+        int n_L = 0;
+        while (n_L < TP_WINSUM_MAX_L && a.winsum_L[n_L] > 0) ++n_L;
+        hipError_t e = tp_window_sums_launch(a.prefix, (double*)a.winsum, a.prefix_nblk, (size_t)(NS * (NS + 1) / 2) * SB * SB,
+                                             a.winsum_L, n_L, stream);
+        if (e != hipSuccess) return e;
     }
     if (conj) {
         const int nci = (a.k + 63) / 64;

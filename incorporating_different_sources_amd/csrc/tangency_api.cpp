@@ -169,8 +169,9 @@ tp_kargs_t make_kargs(tp_batch_t b) {
     a.prefix_nblk = b->prefix_nblk;
     a.winsum = nullptr;
     for (int i = 0; i < 4; ++i) a.winsum_L[i] = 0;
-    if (b->prefix_nblk > 0 && b->p.k <= tp_fused_max_assets()) {      // block Grams first, the block-window tables behind them
-        a.winsum = (const double*)b->prefix.p + (size_t)b->prefix_nblk * tp_fused_slot_doubles(b->p.k);
+    if (b->prefix_nblk > 0) {      // block Grams first, the block-window tables behind them
+        const size_t slot = b->p.k <= tp_fused_max_assets() ? tp_fused_slot_doubles(b->p.k) : tp_tiled_slot_doubles(b->p.k);
+        a.winsum = (const double*)b->prefix.p + (size_t)b->prefix_nblk * slot;
         for (int i = 0; i < 4; ++i) a.winsum_L[i] = b->winsum_L[i];
     }
     a.rhs = (const double*)b->rhs.p;
@@ -512,10 +513,11 @@ static int plan_shared_gram(tp_batch_t b, const tp_inputs_t* in) {
     int nblk = 0;
     size_t bytes = 0;
     for (int i = 0; i < 4; ++i) b->winsum_L[i] = 0;
-    if (p.k <= tp_fused_max_assets()) {
-        // register-tile path: one table of block-window sums per whole-block count that occurs among the windows
-        // (rolling windows of one length have two: 249 rows over 16-row blocks cover 14 or 15 whole blocks)
-        const int blk = TP_PREFIX_BLOCK_ROWS((p.k + 1 + 15) / 16);
+    {
+        // one table of block-window sums per whole-block count that occurs among the windows (rolling windows of one
+        // length have two: 249 rows over 16-row blocks cover 14 or 15 whole blocks)
+        const bool fused = p.k <= tp_fused_max_assets();
+        const int blk = fused ? TP_PREFIX_BLOCK_ROWS((p.k + 1 + 15) / 16) : 16;
         int n_L = 0;
         for (int64_t w = 0; w < b->W; ++w) {
             const long long first = in->start[w], cnt = in->n_rows ? in->n_rows[w] : p.n_r;
@@ -529,9 +531,7 @@ static int plan_shared_gram(tp_batch_t b, const tp_inputs_t* in) {
             }
         }
         if (n_L == 0) return TP_OK;
-        bytes = tp_fused_prefix_bytes(p.k, rows, n_L, &nblk);
-    } else {
-        bytes = tp_tiled_prefix_bytes(p.k, rows, &nblk);
+        bytes = fused ? tp_fused_prefix_bytes(p.k, rows, n_L, &nblk) : tp_tiled_prefix_bytes(p.k, rows, n_L, &nblk);
     }
     if (nblk < 2 || (double)b->W * p.n_r < 3.0 * (double)rows) return TP_OK;
     size_t free_b = 0, total_b = 0;
