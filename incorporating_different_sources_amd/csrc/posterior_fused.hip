@@ -1,6 +1,7 @@
 // posterior_fused.hip - dispatcher of the register-tile fused kernel over the tile count
 // NT = ceil((k+1)/16); the kernels themselves are instantiated in posterior_fused_nt.hip.
 #include "posterior_kernels.h"
+#include <stdlib.h>
 
 #define TP_MAX_NT 15   // NT = 16 would need 163 KiB of LDS (two 32-row staging buffers of 272 doubles)
 
@@ -9,6 +10,14 @@ TP_DECL(1) TP_DECL(2) TP_DECL(3) TP_DECL(4) TP_DECL(5) TP_DECL(6) TP_DECL(7) TP_
 TP_DECL(9) TP_DECL(10) TP_DECL(11) TP_DECL(12) TP_DECL(13) TP_DECL(14) TP_DECL(15)
 
 int tp_fused_max_assets(void) { return 16 * TP_MAX_NT - 1; }
+
+bool tp_use_wave_kernel(int nt) {
+    const char* e = getenv("TP_WAVE_KERNEL");      // read per launch: a test process may flip it between runs
+    if (e && *e) return atoi(e) != 0;
+    // measured on MI355X (tools/sweep_k.py, both kernels in one run, gpurun_out/r03e/sweep.log): tile counts 4..7
+    // (k = 48..111) +10 % .. +55 % for one wave per window; 8 tiles (288 accumulator registers) is where it stops paying
+    return nt >= 4 && nt <= 7;
+}
 
 hipError_t tp_fused_launch(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info,
                            int* want_occupancy) {

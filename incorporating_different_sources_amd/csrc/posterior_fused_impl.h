@@ -1273,11 +1273,15 @@ hipError_t launch_variant(const tp_kargs_t& a, int grid, hipStream_t stream, tp_
     return hipGetLastError();
 }
 
+// launcher of the one-wave-per-window kernel of a tile count (posterior_wave_nt.hip), or nullptr
+typedef hipError_t (*tp_wave_launch_fn)(const tp_kargs_t&, int, hipStream_t, tp_launch_info_t*, bool lean);
+
 template <int NT, int NW>
-hipError_t launch_one(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info) {
+hipError_t launch_one(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info, tp_wave_launch_fn wave) {
     using C = Cfg<NT, NW>;
     static_assert(C::CH == TP_PREFIX_BLOCK_ROWS(NT), "posterior_kernels.h: block rows of the shared Gram prefixes");
-    if (!tp_layout_is_lean(a)) return launch_variant<NT, NW, false>(a, grid, stream, info);
+    if (wave_mode(a) == 2) wave = nullptr;         // read-backs, custom right-hand sides, shifts: the multi-wave kernel
+    if (!tp_layout_is_lean(a)) return wave ? wave(a, grid, stream, info, false) : launch_variant<NT, NW, false>(a, grid, stream, info);
     if (a.winsum != nullptr) {
         // the shared sums first, on the same stream: part of every run, nothing is kept between runs
         static bool attr_done = false;
@@ -1296,7 +1300,7 @@ hipError_t launch_one(const tp_kargs_t& a, int grid, hipStream_t stream, tp_laun
         e = tp_window_sums_launch(a.prefix, (double*)a.winsum, a.prefix_nblk, (size_t)C::NTILES * 256, a.winsum_L, n_L, stream);
         if (e != hipSuccess) return e;
     }
-    return launch_variant<NT, NW, true>(a, grid, stream, info);
+    return wave ? wave(a, grid, stream, info, true) : launch_variant<NT, NW, true>(a, grid, stream, info);
 }
 
 template <int NT, int NW>

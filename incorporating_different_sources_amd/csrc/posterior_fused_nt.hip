@@ -1,6 +1,7 @@
 // posterior_fused_nt.hip - one instantiation of the fused kernel (tile count TP_NT), so that the
 // tile counts compile in parallel.  See posterior_fused_impl.h.
 #include "posterior_fused_impl.h"
+#include <stdlib.h>
 
 #ifndef TP_NT
 #error "compile with -DTP_NT=<tiles per side>"
@@ -8,9 +9,21 @@
 #define TP_CAT2(a, b) a##b
 #define TP_CAT(a, b) TP_CAT2(a, b)
 
+// tile counts that also have the one-wave-per-window kernel (posterior_wave_nt.hip; the Makefile's WAVE_NTS)
+#define TP_WAVE_NT_MIN 4
+#define TP_WAVE_NT_MAX 7
+#if TP_NT >= TP_WAVE_NT_MIN && TP_NT <= TP_WAVE_NT_MAX
+hipError_t TP_CAT(tp_wave_launch_nt, TP_NT)(const tp_kargs_t&, int, hipStream_t, tp_launch_info_t*, bool);
+#define TP_WAVE_FN TP_CAT(tp_wave_launch_nt, TP_NT)
+#else
+#define TP_WAVE_FN nullptr
+#endif
+
 hipError_t TP_CAT(tp_fused_launch_nt, TP_NT)(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info,
                                              int* want_occupancy) {
     constexpr int NW = tp_waves_for_tiles(TP_NT);
     if (want_occupancy) { *want_occupancy = blocks_per_cu<TP_NT, NW>(); return hipSuccess; }
-    return launch_one<TP_NT, NW>(a, grid, stream, info);
+    tp_wave_launch_fn wave = TP_WAVE_FN;
+    if (!tp_use_wave_kernel(TP_NT)) wave = nullptr;
+    return launch_one<TP_NT, NW>(a, grid, stream, info, wave);
 }

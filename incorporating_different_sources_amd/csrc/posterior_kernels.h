@@ -67,6 +67,16 @@ inline size_t tp_fused_prefix_bytes(int k, long long panel_rows, int n_L, int* n
 hipError_t tp_window_sums_launch(const double* G, double* Q, int nblk, size_t slot_doubles, const int* L, int n_L,
                                  hipStream_t stream);
 
+// which register-tile kernel runs a tile count: the one-wave-per-window kernel (posterior_wave_impl.h) or the
+// multi-wave kernel (posterior_fused_impl.h); TP_WAVE_KERNEL=0 / 1 in the environment overrides it (A/B measurements)
+bool tp_use_wave_kernel(int nt);
+// 0 / 1: a plain conjugate / Jeffreys batch (weights, statuses, aux only) - what the one-wave kernel is built for;
+// 2: a batch with a matrix read-back, a custom right-hand side, tp_batch_keep_rhs, a shift or a non-default centring
+inline int wave_mode(const tp_kargs_t& a) {
+    const bool plain = a.dbg_S1 == nullptr && a.rhs == nullptr && a.out_rhs == nullptr && a.shift == nullptr && a.center_rows == 0;
+    return plain ? (a.strategy == 0 ? 0 : 1) : 2;
+}
+
 // register-tile fused kernel (posterior_fused.hip): k <= tp_fused_max_assets()
 int tp_fused_max_assets(void);
 hipError_t tp_fused_launch(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info,

@@ -1,0 +1,728 @@
+#pragma once
+// posterior_wave_impl.h - ONE wavefront per rolling window (register-tile path, small tile counts).
+//
+// The multi-wave kernel of posterior_fused_impl.h spreads the tiles of a window over 4 waves: every staged row
+// goes global -> registers -> LDS -> MFMA operand, every phase ends at a workgroup barrier, and during the
+// serial phases (the 16-pivot elimination of a diagonal tile, the back substitution) three of the four waves
+// of a window are parked (61 % of all wave cycles, profiles/r02_final_pmc_stall_fused_k100.txt).
+//
+// Here a window is ONE wave that owns the whole upper triangle of the bordered matrix (NT (NT+1)/2 accumulator
+// tiles = 224 registers at NT = 7, in the 512-entry unified VGPR/AGPR file at one wave per SIMD):
+//   * the MFMA operands of a 4-row k-step are loaded straight from the panels: lane (fq, fr) reads row 4s+fq,
+//     column 16i+fr - one 8-byte load per 16-column group IS the A/B operand of every tile in that tile row /
+//     column.  No LDS staging, no barrier, three k-steps of loads in flight;
+//   * register r of an accumulator tile holds rows 4r..4r+3 of the tile in exactly the MFMA operand layout, so
+//     the block row R_jJ = M A_jJ and the trailing update A_IJ -= R_jI' R_jJ of the blocked Cholesky take their
+//     operands from the accumulators themselves - the factorisation touches LDS only for the 16x16 diagonal
+//     tile (to turn it into one column per lane for the pivot chain) and for M = R_jj^-T;
+//   * the back substitution runs along block ROWS: lane-local products over the tiles of the row, one 16-lane
+//     DPP reduction per register, and w_I = M' z by MFMA with z as the A operand - no partial sums through LDS;
+//   * no __syncthreads anywhere.
+// Same arithmetic as the multi-wave kernel per matrix element (same k-step order, same elimination), ref:LINE
+// cites /root/reference/src/portfolio_calculations.py as there.
+#include "posterior_fused_impl.h"
+
+namespace {
+
+template <int NT_>
+struct WCfg {
+    static constexpr int NT = NT_;
+    static constexpr int KP = 16 * NT;
+    static constexpr int NTILES = NT * (NT + 1) / 2;
+    static constexpr int MLD = 17;                               // row stride of an M block (conflict-free both ways)
+    static constexpr int OFF_M = 0;                              // [NT][16][MLD]  M_j = R_jj^-T, row-major
+    static constexpr int OFF_DG = OFF_M + NT * 16 * MLD;         // [16][16] diagonal tile handed to the pivot chain
+    static constexpr int OFF_IDT = OFF_DG + 256;                 // [16][16] identity
+    static constexpr int OFF_VEC = OFF_IDT + 256;                // [KP] column sums / Jeffreys t / y
+    static constexpr int LDS_DOUBLES = OFF_VEC + KP;
+    static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
+};
+
+// row-major index of upper-triangle tile (I, J), I <= J - the numbering of the shared Gram tables
+constexpr int wtile(int NT, int I, int J) { return I * NT - I * (I - 1) / 2 + (J - I); }
+
+// The MFMAs of the Gram loops are inline assembly, which the compiler's hazard recogniser does not see: a
+// v_mfma_f64_16x16x4 result may be read by anything but the SrcC of the next MFMA on the same registers only 19
+// wait states after issue (what hipcc inserts behind the builtin).  Every pass over rows ends here; the asm
+// "modifies" every tile, so no later use of an accumulator can be scheduled in front of the wait.
+// s_nop 1: a VGPR written by a vector instruction may be read as an MFMA operand two wait states later at the earliest
+// (hipcc puts the same s_nop in front of the builtin); the asm carries it because the compiler cannot see the hazard.
+__device__ __forceinline__ void wave_mfma_agpr(d4& c, double a, double b) {
+    asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void wave_settle14(d4& c0, d4& c1, d4& c2, d4& c3, d4& c4, d4& c5, d4& c6, d4& c7, d4& c8, d4& c9,
+                                              d4& c10, d4& c11, d4& c12, d4& c13) {
+    asm volatile("s_nop 15\n\ts_nop 7" : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3), "+a"(c4), "+a"(c5), "+a"(c6), "+a"(c7), "+a"(c8),
+                 "+a"(c9), "+a"(c10), "+a"(c11), "+a"(c12), "+a"(c13));
+}
+__device__ __forceinline__ void wave_settle1(d4& c0) { asm volatile("s_nop 15\n\ts_nop 7" : "+a"(c0)); }
+// Entering a row loop: hand the loop-carried accumulators over as AGPR values (an empty asm that "modifies" them), so
+// that the loop's phi nodes become AGPR phis; otherwise the accumulators live in VGPRs across the back edge and are
+// copied into AGPRs for the asm MFMAs on every iteration.
+__device__ __forceinline__ void wave_pin1(d4& c0) { asm volatile("" : "+a"(c0)); }
+template <int NT>
+__device__ __forceinline__ void wave_pin(d4 (&acc)[WCfg<NT>::NTILES]) {
+    static_for<0, WCfg<NT>::NTILES>([&](auto tc) __attribute__((always_inline)) { wave_pin1(acc[decltype(tc)::value]); });
+}
+template <int NT>
+__device__ __forceinline__ void wave_settle(d4 (&acc)[WCfg<NT>::NTILES]) {
+    constexpr int NTL = WCfg<NT>::NTILES;
+    static_for<0, (NTL + 13) / 14>([&](auto gc) __attribute__((always_inline)) {
+        constexpr int b = 14 * decltype(gc)::value;
+        if constexpr (b + 14 <= NTL) {
+            wave_settle14(acc[b], acc[b + 1], acc[b + 2], acc[b + 3], acc[b + 4], acc[b + 5], acc[b + 6], acc[b + 7], acc[b + 8],
+                          acc[b + 9], acc[b + 10], acc[b + 11], acc[b + 12], acc[b + 13]);
+        } else {
+            static_for<b, NTL>([&](auto tc) __attribute__((always_inline)) { wave_settle1(acc[decltype(tc)::value]); });
+        }
+    });
+}
+
+struct WRows {
+    const double* base;     // panel
+    long long ld;           // leading dimension (doubles)
+    const int* ridx;        // explicit rows of this window, or nullptr
+    long long first;        // first row (contiguous)
+    const double* sub_row;  // per-row subtrahend (rf_adj) or nullptr
+    int count;              // rows
+    int count0;             // contiguous, two row ranges: staged rows r >= count0 are panel rows first + r + jump
+    int jump;
+};
+
+// One pass over the rows of a window: acc(I,J) += rows[:, I]' rows[:, J], 4 rows per k-step.
+//  HF:   intraday rows, shifted by `shift` (the window's first row, or its column means), column k carries
+//        u_r = (y_r - shift).w0 and - when `ones` - column k+1 carries ones (one-pass centring, phase C)
+//  !HF:  daily rows minus the per-row risk-free adjustment, column k carries ones (t = X'1, ref:222)
+template <int NT, bool HF, bool LEAN>
+__device__ __forceinline__ void wave_gram(const WRows& src, const int* __restrict__ cols, int k, int lane,
+                                          const double (&shift)[NT], const double (&w0v)[NT], bool ones,
+                                          d4 (&acc)[WCfg<NT>::NTILES]) {
+    constexpr int kI = NT - 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int kc = k - 16 * kI;
+    const bool cvl = fr < kc;
+    const double border = HF ? ((ones && fr == kc + 1) ? 1.0 : 0.0) : ((fr == kc) ? 1.0 : 0.0);
+    const int nks = (src.count + 3) >> 2;
+    const bool has_sub = !HF && src.sub_row != nullptr;
+
+    // column offsets (doubles) of this lane in the NT column groups; padding columns re-read column k-1
+    long long coff[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int c = 16 * i + fr;
+        const int cl = c < k ? c : k - 1;
+        coff[i] = (!LEAN && cols) ? (long long)cols[cl] : (long long)cl;
+    }
+    auto load = [&](double (&v)[NT], double& sub, int ks) __attribute__((always_inline)) {
+        int r = 4 * ks + fq;
+        r = r < src.count ? r : src.count - 1;                      // rows past the end re-read the last row (masked below)
+        long long row;
+        if (LEAN) row = src.first + r + (r >= src.count0 ? src.jump : 0);
+        else row = src.ridx ? (long long)src.ridx[r] : src.first + r;
+        const double* p = src.base + row * src.ld;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) v[i] = p[coff[i]];
+        sub = 0.0;
+        if (has_sub) sub = src.sub_row[r];
+    };
+    // MASK: the k-step may hold rows past the end (only the last three k-steps of a pass are built with it)
+    auto step = [&](double (&v)[NT], double sub, int ks, auto maskc) __attribute__((always_inline)) {
+        constexpr bool MASK = decltype(maskc)::value != 0;
+        if (HF) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) v[i] -= shift[i];
+        } else if (has_sub) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) v[i] -= sub;                // ref:57
+        }
+        v[kI] = cvl ? v[kI] : border;
+        if (MASK) {
+            const bool rv = 4 * ks + fq < src.count;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) v[i] = rv ? v[i] : 0.0;
+        }
+        if (HF) {
+            double z = 0.0;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) z = fma(v[i], w0v[i], z);
+            z = rowgroup_sum16(z);
+            if (fr == kc) v[kI] = z;                                 // u_r = (y_r - shift).w0
+        }
+        static_for<0, NT>([&](auto Ic) __attribute__((always_inline)) {
+            constexpr int I = decltype(Ic)::value;
+            static_for<I, NT>([&](auto Jc) __attribute__((always_inline)) {
+                constexpr int J = decltype(Jc)::value;
+                constexpr int t = wtile(NT, I, J);
+                // accumulators pinned to the AGPR half of the register file: left to itself the allocator moved the
+                // whole accumulator set between VGPRs and AGPRs inside this loop (497 v_accvgpr moves per 84 MFMAs)
+                wave_mfma_agpr(acc[t], v[I], v[J]);
+            });
+        });
+    };
+
+    if (nks <= 0) return;
+    // Three register sets rotate through load -> (two k-steps of MFMAs) -> use.  The main loop runs whole triples of
+    // full k-steps as ONE basic block (loads past the end re-read the last row); at most three k-steps remain.
+    double va[NT], vb[NT], vc[NT];
+    double sa = 0.0, sb = 0.0, sc = 0.0;
+    load(va, sa, 0);
+    load(vb, sb, 1);
+    wave_pin<NT>(acc);
+    int ks = 0;
+#pragma nounroll
+    for (; 4 * (ks + 3) <= src.count; ks += 3) {
+        load(vc, sc, ks + 2);
+        step(va, sa, ks, ic<0>{});
+        load(va, sa, ks + 3);
+        step(vb, sb, ks + 1, ic<0>{});
+        load(vb, sb, ks + 4);
+        step(vc, sc, ks + 2, ic<0>{});
+    }
+    if (ks < nks) {
+        if (ks + 2 < nks) load(vc, sc, ks + 2);
+        step(va, sa, ks, ic<1>{});
+        if (ks + 1 < nks) step(vb, sb, ks + 1, ic<1>{});
+        if (ks + 2 < nks) step(vc, sc, ks + 2, ic<1>{});
+    }
+    wave_settle<NT>(acc);
+}
+
+// MODE 0: conjugate, 1: Jeffreys - the plain product paths, compiled without the read-back / custom right-hand side /
+// shift branches: every branch that merges two versions of the accumulators costs register copies or spills here (one
+// kernel with all of them decided at run time, MODE 2, needs 2.2 KB of scratch per lane against 44 bytes, and spill code
+// next to the inline-assembly MFMAs is exactly what the hazard argument of wave_settle cannot cover).  MODE 2 is therefore
+// not instantiated: batches that ask for a matrix read-back, a custom right-hand side, tp_batch_keep_rhs or a shift run
+// on the multi-wave kernel (wave_mode / launch_one).
+template <int NT, bool LEAN, int MODE>
+__device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* lds) {
+    constexpr bool FULL = MODE == 2;
+    using C = WCfg<NT>;
+    const int lane = threadIdx.x;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int k = A.k;
+    __builtin_assume(k >= 16 * (NT - 1));
+    __builtin_assume(k <= 16 * NT - 1);
+    constexpr int kI = NT - 1;
+    const int kc = k - 16 * kI;
+    const int NTB = (kc == 0) ? NT - 1 : NT;
+    const bool colv = fr < kc;
+    // XCD-aware workgroup -> window map (see posterior_fused_impl.h): one contiguous window range per XCD
+    const long long per_xcd = (A.w_count + 7) >> 3;
+    const long long wl = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((long long)(blockIdx.x >> 3) >= per_xcd || wl >= A.w_count) return;
+    const long long w = A.w_first + wl;
+    const int tid0 = lane;
+    (void)tid0;
+
+    const int* cols = (!LEAN && A.col_idx) ? A.col_idx + w * k : nullptr;
+    d4 acc[C::NTILES];
+    static_for<0, C::NTILES>([&](auto tc) __attribute__((always_inline)) { acc[decltype(tc)::value] = d4{0.0, 0.0, 0.0, 0.0}; });
+    // AGPR values from the first definition on: where two paths of the kernel meet, the accumulators must arrive as AGPR
+    // values on both, or the merge keeps all of them in VGPRs (and spills)
+    wave_pin<NT>(acc);
+
+    // identity tile for the pivot chain (read after many waits on this wave's own LDS traffic)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = lane + 64 * i;
+        lds[C::OFF_IDT + e] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
+    }
+
+    double n0 = 0.0, cc = 0.0, q0 = 0.0;
+    const bool conj = MODE == 0 ? true : MODE == 1 ? false : (A.strategy == 0);
+    const int dbg = (FULL && A.dbg_S1 != nullptr && w == A.dbg_w) ? A.dbg_mode : 0;
+
+    auto dump_matrix = [&]() __attribute__((always_inline)) {
+        static_for<0, NT>([&](auto Ic) __attribute__((always_inline)) {
+            constexpr int I = decltype(Ic)::value;
+            static_for<I, NT>([&](auto Jc) __attribute__((always_inline)) {
+                constexpr int J = decltype(Jc)::value;
+                constexpr int t = wtile(NT, I, J);
+                const int gj = 16 * J + fr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = 16 * I + fq + 4 * r;
+                    if (gi < k && gj < k) {
+                        A.dbg_S1[(long long)gi * k + gj] = acc[t][r];
+                        A.dbg_S1[(long long)gj * k + gi] = acc[t][r];
+                    }
+                    if (gi < k && gj == k) A.dbg_S1[(long long)k * k + gi] = acc[t][r];
+                }
+            });
+        });
+    };
+    // value of element (row kc, column kc) of tile (kI, kI): the corner of the bordered matrix
+    auto corner = [&]() __attribute__((always_inline)) {
+        constexpr int t = wtile(NT, kI, kI);
+        const int rr = kc >> 2;
+        const double x = rr == 0 ? acc[t][0] : rr == 1 ? acc[t][1] : rr == 2 ? acc[t][2] : acc[t][3];
+        return readlane_d(x, __builtin_amdgcn_readfirstlane(16 * (kc & 3) + kc));
+    };
+
+    TP_MARK(0);
+    if (conj && dbg != 2) {
+        n0 = A.n0[w];
+        WRows hs;
+        hs.base = A.hf_panel; hs.ld = A.hf_ld;
+        hs.ridx = (!LEAN && A.hf_row_idx) ? A.hf_row_idx + w * (long long)A.m : nullptr;
+        hs.first = A.hf_start ? A.hf_start[w] : 0;
+        hs.sub_row = nullptr;
+        hs.count = A.hf_count ? A.hf_count[w] : A.m;
+        hs.count0 = 0x7fffffff; hs.jump = 0;
+        // ---- phase A: shift row (one-pass centred scatter, see posterior_fused_impl.h) or column means (k+1 = 0 mod 16)
+        const bool shifted = kc < 15;
+        double shift[NT], w0v[NT];
+        {
+            const long long row0 = hs.ridx ? (long long)hs.ridx[0] : hs.first;
+            const double* p0 = hs.base + row0 * (long long)hs.ld;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int c = 16 * i + fr;
+                const int cl = c < k ? c : k - 1;
+                const double sv = p0[cols ? cols[cl] : cl];
+                const double wv = A.w0[w * k + cl];
+                shift[i] = (c < k) ? sv : 0.0;
+                w0v[i] = (c < k) ? wv : 0.0;
+            }
+        }
+        if (!shifted) {
+            // two-pass form: column means first (every lane group sums its rows, the four groups meet by shuffles)
+            double cs[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) cs[i] = 0.0;
+            const int nks = (hs.count + 3) >> 2;
+            for (int ks = 0; ks < nks; ++ks) {
+                const int r = 4 * ks + fq;
+                const int rc = r < hs.count ? r : hs.count - 1;
+                const long long row = hs.ridx ? (long long)hs.ridx[rc] : hs.first + rc;
+                const double* p = hs.base + row * (long long)hs.ld;
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const int c = 16 * i + fr;
+                    const int cl = c < k ? c : k - 1;
+                    const double x = p[cols ? cols[cl] : cl];
+                    cs[i] += (r < hs.count) ? x : 0.0;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                double s = cs[i];
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                shift[i] = (16 * i + fr < k) ? s / (double)hs.count : 0.0;
+            }
+        }
+        TP_MARK(1);
+        // ---- phase B: Gram of the shifted / centred intraday rows
+        wave_gram<NT, true, LEAN>(hs, cols, k, lane, shift, w0v, shifted, acc);
+        TP_MARK(2);
+        // ---- phase C: rank-one term of the centring (one-pass form); q0, c, scaling (ref:333, 415-418).  ONE pass over
+        // the tiles, a tile row at a time: vector instructions cannot read AGPRs, every tile visits the VGPR half on its
+        // way - all 224 registers at once would spill, and a spill reload costs this lone wave a full memory round trip.
+        const double invm = 1.0 / (double)hs.count;
+        double tj[NT];
+#pragma unroll
+        for (int J = 0; J < NT; ++J) tj[J] = 0.0;
+        double cz = corner();                                       // z'z = w0'C w0 (before the rank-one term)
+        if (shifted) {
+            // column k+1 holds t_i = sum_r (y_r - s)_i for the asset columns and sum_r u_r in row k
+            static_for<0, NT>([&](auto Ic) __attribute__((always_inline)) {
+                constexpr int I = decltype(Ic)::value;
+                constexpr int t = wtile(NT, I, kI);
+                if (fr == kc + 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        lds[C::OFF_VEC + 16 * I + fq + 4 * r] = (I < kI || fq + 4 * r <= kc) ? acc[t][r] : 0.0;
+                }
+            });
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int J = 0; J < NT; ++J) tj[J] = lds[C::OFF_VEC + 16 * J + fr];      // zero beyond column k
+            const double tk = lds[C::OFF_VEC + k];
+            cz = fma(-(tk * invm), tk, cz);
+        }
+        const double mm = (double)hs.count;
+        const double sc = n0 * (mm / (mm - 1.0));
+        q0 = sc * cz;
+        const double a = n0 + k + 2;
+        cc = (2 * n0) / (a + sqrt(a * a + 4 * n0 * q0));
+        // S0 = sc * C on the real columns, c * sc * C w0 in the border column, zero beyond
+        const double fcol = colv ? sc : ((fr == kc) ? cc * sc : 0.0);
+        static_for<0, NT>([&](auto Ic) __attribute__((always_inline)) {
+            constexpr int I = decltype(Ic)::value;
+            double ti[4] = {0.0, 0.0, 0.0, 0.0};
+            if (shifted) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ti[r] = -(lds[C::OFF_VEC + 16 * I + fq + 4 * r] * invm);
+            }
+            static_for<I, NT>([&](auto Jc) __attribute__((always_inline)) {
+                constexpr int J = decltype(Jc)::value;
+                constexpr int t = wtile(NT, I, J);
+                d4 x = acc[t];
+                if (shifted) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[r] = fma(ti[r], tj[J], x[r]);
+                }
+                if constexpr (J < kI) {
+                    x *= sc;
+                } else if constexpr (I < kI) {
+                    x *= fcol;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[r] *= (fq + 4 * r < kc) ? fcol : 0.0;
+                }
+                acc[t] = x;
+                wave_pin1(acc[t]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        __builtin_amdgcn_wave_barrier();
+        if (dbg == 1) { dump_matrix(); return; }
+    }
+    TP_MARK(3);
+    // ---- phase D: daily Gram (ref:180) + t in the border column (ref:222)
+    {
+        WRows ds;
+        ds.base = A.panel; ds.ld = A.panel_ld;
+        ds.ridx = (!LEAN && A.row_idx) ? A.row_idx + w * (long long)A.n_r : nullptr;
+        ds.first = A.start ? A.start[w] : 0;
+        ds.sub_row = A.rf_adj ? A.rf_adj + w * (long long)A.n_r : nullptr;
+        ds.count = A.n_rows ? A.n_rows[w] : A.n_r;
+        ds.count0 = 0x7fffffff; ds.jump = 0;
+        const double none[NT] = {};
+        bool shared = false;
+        const double* q = nullptr;
+        if constexpr (LEAN) {
+            // shared block-window sums (posterior_fused_impl.h, phase D): only the rows in front of the first whole
+            // aligned 16-row block and behind the last one go through the MFMAs
+            constexpr int BLK = 16;
+            const long long b0 = (ds.first + BLK - 1) / BLK, b1 = (ds.first + ds.count) / BLK;
+            const int Lw = (int)(b1 - b0);
+            const int li = Lw == A.winsum_L[0] ? 0 : Lw == A.winsum_L[1] ? 1 : Lw == A.winsum_L[2] ? 2 : Lw == A.winsum_L[3] ? 3 : -1;
+            shared = A.winsum != nullptr && Lw > 0 && li >= 0;
+            if (shared) {
+                ds.count0 = (int)(BLK * b0 - ds.first);
+                ds.jump = (int)(BLK * b1 - ds.first) - ds.count0;
+                ds.count = ds.count0 + (int)(ds.first + ds.count - BLK * b1);
+                q = A.winsum + ((long long)li * A.prefix_nblk + b0) * ((long long)C::NTILES * 256);
+            }
+        }
+        TP_MARK(32);
+        wave_gram<NT, false, LEAN>(ds, cols, k, lane, none, none, false, acc);
+        TP_MARK(33);
+        if (LEAN && shared) {
+            // ONE table slot Q_L[b0]: [tile][2][64 lanes][2] doubles, two 16-byte reads per tile, 7 tiles in flight
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            const d2* pq = (const d2*)q + lane;
+            constexpr int GRP = 7;
+            static_for<0, (C::NTILES + GRP - 1) / GRP>([&](auto gc) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value;
+                d2 v2[GRP][2];
+                static_for<0, GRP>([&](auto ec) __attribute__((always_inline)) {
+                    constexpr int t = g * GRP + decltype(ec)::value;
+                    if constexpr (t < C::NTILES) {
+                        v2[decltype(ec)::value][0] = pq[(long long)t * 128];
+                        v2[decltype(ec)::value][1] = pq[(long long)t * 128 + 64];
+                    }
+                });
+                static_for<0, GRP>([&](auto ec) __attribute__((always_inline)) {
+                    constexpr int e = decltype(ec)::value;
+                    constexpr int t = g * GRP + e;
+                    if constexpr (t < C::NTILES) {
+                        d4 x = acc[t];
+                        x[0] += v2[e][0][0]; x[1] += v2[e][0][1];
+                        x[2] += v2[e][1][0]; x[3] += v2[e][1][1];
+                        acc[t] = x;
+                        wave_pin1(acc[t]);
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+    }
+    TP_MARK(34);
+    // rows >= k of the bordered matrix are never pivots: clear them (they hold 1'X, n_r, ...)
+    static_for<0, NT>([&](auto Ic) __attribute__((always_inline)) {
+        constexpr int I = decltype(Ic)::value;
+        constexpr int t = wtile(NT, I, kI);
+        if constexpr (I == kI) {
+            d4 x = acc[t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = (fq + 4 * r >= kc) ? 0.0 : x[r];
+            acc[t] = x;
+            wave_pin1(acc[t]);
+        }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    if (dbg == 2) { dump_matrix(); return; }
+
+    if (!conj) {
+        // ---- phase E: J = T - t t'/N (ref:600-601); t stays in the border column (ref:606 rhs)
+        static_for<0, NT>([&](auto Ic) __attribute__((always_inline)) {
+            constexpr int I = decltype(Ic)::value;
+            constexpr int t = wtile(NT, I, kI);
+            if (fr == kc) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lds[C::OFF_VEC + 16 * I + fq + 4 * r] = acc[t][r];
+            }
+        });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const double invN = !FULL ? 1.0 / (double)A.N : A.center_rows == 2 ? 0.0
+                          : 1.0 / (double)(A.center_rows ? (A.n_rows ? A.n_rows[w] : A.n_r) : A.N);
+        const double sh_d = (FULL && A.shift) ? A.shift[2 * w] : 0.0;
+        const double sh_e = (FULL && A.shift) ? A.shift[2 * w + 1] : 0.0;
+        double tj[NT];
+#pragma unroll
+        for (int J = 0; J < NT; ++J) tj[J] = lds[C::OFF_VEC + 16 * J + fr];
+        static_for<0, NT>([&](auto Ic) __attribute__((always_inline)) {
+            constexpr int I = decltype(Ic)::value;
+            double ti[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ti[r] = lds[C::OFF_VEC + 16 * I + fq + 4 * r];
+            static_for<I, NT>([&](auto Jc) __attribute__((always_inline)) {
+                constexpr int J = decltype(Jc)::value;
+                constexpr int t = wtile(NT, I, J);
+                d4 x = acc[t];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool on = (J < kI || colv) && (I < kI || fq + 4 * r < kc);
+                    const double add = sh_e + ((I == J && fq + 4 * r == fr) ? sh_d : 0.0);
+                    x[r] += on ? add - invN * (ti[r] * tj[J]) : 0.0;
+                }
+                acc[t] = x;
+                wave_pin1(acc[t]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (FULL && A.rhs != nullptr) {
+        static_for<0, NT>([&](auto Ic) __attribute__((always_inline)) {
+            constexpr int I = decltype(Ic)::value;
+            constexpr int t = wtile(NT, I, kI);
+            if (fr == kc) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = 16 * I + fq + 4 * r;
+                    const int gl = gi < k ? gi : k - 1;
+                    const double x = A.rhs[w * k + gl];
+                    acc[t][r] = (gi < k) ? x : 0.0;
+                }
+            }
+            wave_pin1(acc[t]);
+        });
+    }
+    if (FULL && A.out_rhs != nullptr) {
+        static_for<0, NT>([&](auto Ic) __attribute__((always_inline)) {
+            constexpr int I = decltype(Ic)::value;
+            constexpr int t = wtile(NT, I, kI);
+            if (fr == kc) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gi = 16 * I + fq + 4 * r;
+                    if (gi < k) A.out_rhs[w * k + gi] = acc[t][r];
+                }
+            }
+        });
+    }
+    if (dbg == 3) dump_matrix();
+
+    TP_MARK(4);
+    // ---- phase F: blocked upper Cholesky S1 = R'R with the border column riding along (y = R^-T b)
+    bool bad = false;
+    static_for<0, NT>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        if (j < NTB) {
+            const int npiv = (k - 16 * j < 16) ? (k - 16 * j) : 16;
+            constexpr int tjj = wtile(NT, j, j);
+            // (1) diagonal tile -> LDS (row-major) -> one column per lane; lanes 16-31 take the identity's columns
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[C::OFF_DG + (fq + 4 * r) * 16 + fr] = acc[tjj][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int c16 = lane & 15;
+            double a[16];
+            const double* src = (lane < 16) ? (lds + C::OFF_DG) : (lds + C::OFF_IDT);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a[i] = src[i * 16 + c16];
+            // (2) 16 pivots: multipliers by v_readlane, rsqrt (v_rsq_f64 + one cubic step) with look-ahead
+            double d0 = readlane_d(a[0], 0);
+            bad |= !(d0 > 0.0);
+            double rinv = rsqrt_cubic(d0);
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                if (p < npiv) {
+                    a[p] *= rinv;
+                    double rinv_next = 1.0;
+                    if (p + 1 < 16) {
+                        const double s1 = readlane_d(a[p], p + 1);
+                        a[p + 1] = fma(-s1, a[p], a[p + 1]);
+                        double dn = readlane_d(a[p + 1], p + 1);
+                        const bool live = p + 1 < npiv;
+                        bad |= live && !(dn > 0.0);
+                        dn = live ? dn : 1.0;
+                        rinv_next = rsqrt_cubic(dn);
+                    }
+#pragma unroll
+                    for (int i = p + 2; i < 16; ++i) {
+                        const double sI = readlane_d(a[p], i);
+                        a[i] = fma(-sI, a[p], a[i]);
+                    }
+                    rinv = rinv_next;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // M_j = R_jj^-T (lower triangular), rows past the last pivot zeroed
+            if (lane >= 16 && lane < 32) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) lds[C::OFF_M + (j * 16 + i) * C::MLD + c16] = (i < npiv) ? a[i] : 0.0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // (3) block row j: R_jJ = M A_jJ (A operand: M, B operand: the tile's own registers)
+            double mop[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mop[r] = lds[C::OFF_M + (j * 16 + fr) * C::MLD + 4 * r + fq];    // M[fr][4r + fq]
+            static_for<j, NT>([&](auto Jc) __attribute__((always_inline)) {
+                constexpr int J = decltype(Jc)::value;
+                if constexpr (J > j || j == kI) {        // R_jj itself is never used again (the solves use M_j)
+                    constexpr int t = wtile(NT, j, J);
+                    d4 rj = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rj = __builtin_amdgcn_mfma_f64_16x16x4f64(mop[r], acc[t][r], rj, 0, 0, 0);
+                    acc[t] = rj;
+                }
+            });
+            // (4) trailing update A_IJ -= R_jI' R_jJ, operands straight from the block row's registers
+            static_for<j + 1, NT>([&](auto Ic) __attribute__((always_inline)) {
+                constexpr int I = decltype(Ic)::value;
+                static_for<I, NT>([&](auto Jc) __attribute__((always_inline)) {
+                    constexpr int J = decltype(Jc)::value;
+                    constexpr int t = wtile(NT, I, J), tI = wtile(NT, j, I), tJ = wtile(NT, j, J);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[tI][r], acc[tJ][r], acc[t], 0, 0, 1);
+                });
+            });
+        }
+    });
+
+    TP_MARK(5);
+    // ---- phase G: y, q1 = y'y (ref:574), back substitution R w = y along block rows
+    double q1 = 0.0;
+    double wcol[NT];          // wcol[J] = w[16 J + fr] in every lane group
+#pragma unroll
+    for (int J = 0; J < NT; ++J) wcol[J] = 0.0;
+    {
+        double q1p = 0.0;
+        static_for<0, NT>([&](auto Ic) __attribute__((always_inline)) {
+            constexpr int I = decltype(Ic)::value;
+            constexpr int t = wtile(NT, I, kI);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double y = (fr == kc && (I < kI || fq + 4 * r < kc)) ? acc[t][r] : 0.0;
+                q1p = fma(y, y, q1p);
+            }
+        });
+        q1 = wave_sum64(q1p);
+    }
+    static_for<0, NT>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int Ib = NT - 1 - decltype(ic)::value;
+        if (Ib < NTB) {
+            constexpr int tb = wtile(NT, Ib, kI);
+            // z_r (rows 4r + fq of block Ib) = y - sum_{J > Ib} R_{Ib,J} w_J: lane-local products, ONE reduction per register
+            double z[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double u = 0.0;
+                static_for<Ib + 1, NT>([&](auto Jc) __attribute__((always_inline)) {
+                    constexpr int J = decltype(Jc)::value;
+                    constexpr int t = wtile(NT, Ib, J);
+                    if (J < NTB) u = fma(acc[t][r], wcol[J], u);
+                });
+                // the border column's y sits in lane fr == kc of its 16-lane row group: it joins the same reduction
+                const double y = (fr == kc && (Ib < kI || fq + 4 * r < kc)) ? acc[tb][r] : 0.0;
+                z[r] = rowgroup_sum16(y - u);
+            }
+            // w_Ib = M' z by MFMA: A[i][kk] = z[4r + kk] (any i), B[kk][n] = M[4r + kk][n]  =>  every row of the result is w'
+            d4 wt = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double mrow = lds[C::OFF_M + (Ib * 16 + 4 * r + fq) * C::MLD + fr];
+                wt = __builtin_amdgcn_mfma_f64_16x16x4f64(z[r], mrow, wt, 0, 0, 0);
+            }
+            wcol[Ib] = wt[0];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    });
+
+    TP_MARK(6);
+    // ---- phase H: weights, status, aux (ref:572-575, 836 / 849)
+    {
+        const double n1 = n0 + (double)A.N;
+        const double denom = n1 - q1;
+        bool nonfinite = false;
+        static_for<0, NT>([&](auto Ic) __attribute__((always_inline)) {
+            constexpr int I = decltype(Ic)::value;
+            const int gi = 16 * I + fr;
+            double out;
+            if (conj) out = 1.0 / A.gamma * ((n1 + k + 2) * wcol[I] / denom);
+            else out = 1.0 / A.gamma * wcol[I];
+            if (fq == (I & 3) && gi < k) {
+                A.weights[w * k + gi] = out;
+                if (!isfinite(out)) nonfinite = true;
+            }
+        });
+        const bool anybad = __any(nonfinite ? 1 : 0) != 0;
+        const bool notpd = __any(bad ? 1 : 0) != 0;
+        if (lane == 0) {
+            int st = TP_KSTATUS_OK;
+            if (notpd) st = TP_KSTATUS_NOT_PD;
+            else if (anybad) st = TP_KSTATUS_NONFINITE;
+            else if (conj && !(denom > 0.0)) st = TP_KSTATUS_BAD_DENOM;
+            A.status[w] = st;
+            if (A.aux) {
+                double* ax = A.aux + w * 8;
+                ax[0] = n0; ax[1] = conj ? n1 : 0.0; ax[2] = cc; ax[3] = q0; ax[4] = q1;
+                ax[5] = conj ? denom : 0.0; ax[6] = 0.0; ax[7] = 0.0;
+            }
+        }
+    }
+    TP_MARK(7);
+}
+
+template <int NT, bool LEAN, int MODE>
+__global__ void __launch_bounds__(64, 1) posterior_wave_kernel(const tp_kargs_t A) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    wave_window_body<NT, LEAN, MODE>(A, lds);
+}
+
+template <int NT, bool LEAN, int MODE>
+hipError_t wave_launch_mode(const tp_kargs_t& a, int grid8, hipStream_t stream) {
+    using C = WCfg<NT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)posterior_wave_kernel<NT, LEAN, MODE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((posterior_wave_kernel<NT, LEAN, MODE>), dim3(grid8), dim3(64), C::LDS_BYTES, stream, a);
+    return hipGetLastError();
+}
+
+template <int NT, bool LEAN>
+hipError_t wave_launch_variant(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info) {
+    using C = WCfg<NT>;
+    if (info) { info->grid = grid; info->block = 64; info->lds_bytes = C::LDS_BYTES; info->ntile = NT; }
+    const int grid8 = 8 * ((grid + 7) / 8);
+    switch (wave_mode(a)) {
+        case 0: return wave_launch_mode<NT, LEAN, 0>(a, grid8, stream);
+        case 1: return wave_launch_mode<NT, LEAN, 1>(a, grid8, stream);
+        default: return hipErrorInvalidValue;        // launch_one keeps such batches on the multi-wave kernel
+    }
+}
+
+}  // namespace

@@ -74,3 +74,13 @@ def test_product_package_never_imports_the_oracle():
                 low = line.lower()
                 if "oracle" in low and any(t in low for t in ("import", "#include", "cdll", "-l", "dlopen")):
                     raise AssertionError(f"{f}: product code references the oracle: {line.strip()}")
+
+
+def test_wave_kernel_asm_hazards():
+    """The inline-assembly MFMAs of the one-wave-per-window kernels: no instruction of the generated ISA touches
+    an MFMA destination before its 19 wait states are over (tools/check_mfma_hazards.py on every tile count)."""
+    import subprocess
+    csrc = os.path.join(REPO, "incorporating_different_sources_amd", "csrc")
+    r = subprocess.run(["make", "-j4", "-C", csrc, "hazards"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 hazard finding(s)" in r.stdout and "inline-asm MFMAs" in r.stdout

@@ -39,3 +39,10 @@ print("factorisation, summed cycles per window by block-step segment (median), w
 for wv in range(2):
     m = np.median(fseg[:, wv, :], axis=0)
     print(f"  wave {wv}: hand-over+barrier {m[0]:8.0f}  elimination+barrier {m[1]:8.0f}  trsm+barrier {m[2]:8.0f}  trailing {m[3]:8.0f}  total {m.sum():8.0f}")
+
+# one-wave-per-window kernel: extra stamps inside phase D (slots 32..34: before the edge rows, after them, after the table read)
+full = b.debug_stamps()
+if full[:, 32].any():
+    x = full[:, [3, 32, 33, 34, 4]].astype(np.float64)
+    dd = np.diff(x, axis=1)
+    print("wave kernel, phase D split (median ticks): setup %.0f  edge rows %.0f  table slot %.0f  rest %.0f" % tuple(np.median(dd, axis=0)))
