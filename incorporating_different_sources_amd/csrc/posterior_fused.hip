@@ -14,9 +14,10 @@ int tp_fused_max_assets(void) { return 16 * TP_MAX_NT - 1; }
 bool tp_use_wave_kernel(int nt) {
     const char* e = getenv("TP_WAVE_KERNEL");      // read per launch: a test process may flip it between runs
     if (e && *e) return atoi(e) != 0;
-    // measured on MI355X (tools/sweep_k.py, both kernels in one run, gpurun_out/r03e/sweep.log): tile counts 4..7
-    // (k = 48..111) +10 % .. +55 % for one wave per window; 8 tiles (288 accumulator registers) is where it stops paying
-    return nt >= 4 && nt <= 7;
+    // measured on MI355X (tools/sweep_k.py, both kernels in one run, gpurun_out/r03f/sweep.log): one wave per window
+    // wins at every tile count it is built for: +10 % (k = 8) .. +55 % (k = 55), +24 % at k = 100.  Eight tiles
+    // (288 accumulator registers) no longer fit the AGPR half of the register file.
+    return nt >= 1 && nt <= 7;
 }
 
 hipError_t tp_fused_launch(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info,

@@ -251,12 +251,16 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
             });
         });
     };
-    // value of element (row kc, column kc) of tile (kI, kI): the corner of the bordered matrix
+    // value of element (row kc, column kc) of tile (kI, kI): the corner of the bordered matrix.  All four registers are
+    // read and the SCALAR results selected: a run-time choice among the four vector registers came out of hipcc as a
+    // branch ladder that left the value undefined for kc >= 12 in some instantiations (k = 31, 63: garbage q0).
     auto corner = [&]() __attribute__((always_inline)) {
         constexpr int t = wtile(NT, kI, kI);
+        const int ln = __builtin_amdgcn_readfirstlane(16 * (kc & 3) + kc);
+        const double x0 = readlane_d(acc[t][0], ln), x1 = readlane_d(acc[t][1], ln);
+        const double x2 = readlane_d(acc[t][2], ln), x3 = readlane_d(acc[t][3], ln);
         const int rr = kc >> 2;
-        const double x = rr == 0 ? acc[t][0] : rr == 1 ? acc[t][1] : rr == 2 ? acc[t][2] : acc[t][3];
-        return readlane_d(x, __builtin_amdgcn_readfirstlane(16 * (kc & 3) + kc));
+        return rr == 0 ? x0 : rr == 1 ? x1 : rr == 2 ? x2 : x3;
     };
 
     TP_MARK(0);
@@ -693,8 +697,17 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
     TP_MARK(7);
 }
 
+// Windows (= waves) per SIMD the register allocator is asked to keep: the accumulators take 8 registers per tile, the
+// row pipeline about 100; two or more waves per SIMD also double the vector issue rate (one wave alone issues an fp64
+// vector instruction every ~9 cycles, two get one every ~4.75: tools/coexec_probe.hip).
+#ifdef TP_WAVE_OCC
+constexpr int wave_occupancy(int) { return TP_WAVE_OCC; }
+#else
+constexpr int wave_occupancy(int nt) { return nt <= 3 ? 4 : nt <= 5 ? 2 : 1; }
+#endif
+
 template <int NT, bool LEAN, int MODE>
-__global__ void __launch_bounds__(64, 1) posterior_wave_kernel(const tp_kargs_t A) {
+__global__ void __launch_bounds__(64, wave_occupancy(NT)) posterior_wave_kernel(const tp_kargs_t A) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     wave_window_body<NT, LEAN, MODE>(A, lds);
 }

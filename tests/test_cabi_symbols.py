@@ -80,6 +80,9 @@ def test_wave_kernel_asm_hazards():
     """The inline-assembly MFMAs of the one-wave-per-window kernels: no instruction of the generated ISA touches
     an MFMA destination before its 19 wait states are over (tools/check_mfma_hazards.py on every tile count)."""
     import subprocess
+    import sys
+    tool = os.path.join(REPO, "tools", "check_mfma_hazards.py")
+    assert subprocess.run([sys.executable, tool, "--selftest"]).returncode == 0, "the checker misses its own planted hazard"
     csrc = os.path.join(REPO, "incorporating_different_sources_amd", "csrc")
     r = subprocess.run(["make", "-j4", "-C", csrc, "hazards"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

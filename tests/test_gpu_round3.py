@@ -1,0 +1,93 @@
+"""Round 3: the one-wave-per-window kernel (csrc/posterior_wave_impl.h) against the multi-wave kernel and the oracle.
+-m gpu.  TP_WAVE_KERNEL is read by the library at every launch, so one process can run both kernels."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from incorporating_different_sources_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from incorporating_different_sources_amd import _native
+    return _native
+
+
+@pytest.fixture()
+def kernel_choice():
+    old = os.environ.get("TP_WAVE_KERNEL")
+    yield lambda v: os.environ.__setitem__("TP_WAVE_KERNEL", v)
+    if old is None:
+        os.environ.pop("TP_WAVE_KERNEL", None)
+    else:
+        os.environ["TP_WAVE_KERNEL"] = old
+
+
+def _run(native, strat, k, N, inp, **extra):
+    kw = dict(panel=inp["panel"], start=inp["start"], n_r=inp["n_r"])
+    if strat == "conjugate":
+        kw.update(hf_panel=inp["hf_panel"], hf_start=inp["hf_start"], m=inp["m"], w0=inp["w0"], n0=inp["n0"])
+    kw.update(extra)
+    return native.posterior_batch(strat, k, N, 5.0, **kw)
+
+
+@pytest.mark.parametrize("strat", ["conjugate", "jeffreys"])
+def test_every_universe_size_of_the_wave_kernel(native, kernel_choice, strat):
+    """EVERY k the one-wave kernel serves (1..111: seven tile counts, every position of the border column inside its
+    tile, the two-pass sizes k+1 = 0 mod 16): against the oracle at the flat 1e-10 bound and against the multi-wave
+    kernel (same arithmetic per element: agreement to a few ulps).  A per-instantiation compiler quirk (round 3: the
+    corner read-out at k = 31 and 63) cannot hide between sampled sizes."""
+    worst = 0.0
+    for k in range(1, 112):
+        N = max(2 * k + 10, 40) if strat == "jeffreys" else max(k + 30, 40)
+        inp = synthetic.make_kernel_inputs(k, N, 9, seed=31000 + k)
+        ref, rstat, _ = oracle.posterior_batch_c(strat, k, N, 5.0, **{kk: v for kk, v in dict(
+            panel=inp["panel"], start=inp["start"], n_r=inp["n_r"], hf_panel=inp["hf_panel"], hf_start=inp["hf_start"],
+            m=inp["m"], w0=inp["w0"], n0=inp["n0"]).items() if strat == "conjugate" or kk in ("panel", "start", "n_r")})
+        kernel_choice("0")
+        w_multi, s_multi, a_multi = _run(native, strat, k, N, inp)
+        kernel_choice("1")
+        w_wave, s_wave, a_wave = _run(native, strat, k, N, inp)
+        assert (s_wave == rstat).all() and (s_multi == rstat).all(), (k, s_wave, rstat)
+        np.testing.assert_allclose(w_wave, ref, rtol=0, atol=1e-10, err_msg=f"k={k}")
+        np.testing.assert_allclose(w_wave, w_multi, rtol=0, atol=1e-12, err_msg=f"k={k}")
+        np.testing.assert_allclose(a_wave[:, :6], a_multi[:, :6], rtol=1e-12, atol=1e-300, err_msg=f"k={k}")
+        worst = max(worst, float(np.abs(w_wave - ref).max()))
+    assert worst < 1e-10
+
+
+def test_wave_kernel_index_layout_and_ragged_windows(native, kernel_choice):
+    """The index layout (explicit rows, gathered columns, per-row risk-free adjustment, ragged row counts) on the
+    one-wave kernel: equal to the multi-wave kernel's results and to the oracle."""
+    rng = np.random.default_rng(5)
+    k, N, W = 37, 90, 12
+    inp = synthetic.make_kernel_inputs(60, N, W, seed=77)            # a 60-column panel, 37 gathered columns
+    n_r, m = inp["n_r"], inp["m"]
+    col_idx = np.stack([np.sort(rng.choice(60, k, replace=False)) for _ in range(W)]).astype(np.int32)
+    row_idx = np.stack([inp["start"][w] + np.sort(rng.choice(n_r, n_r, replace=False)) for w in range(W)]).astype(np.int32)
+    n_rows = rng.integers(n_r - 9, n_r + 1, size=W).astype(np.int32)
+    rf_adj = rng.normal(0, 1e-4, size=(W, n_r))
+    w0 = np.abs(rng.normal(size=(W, k))); w0 /= w0.sum(axis=1, keepdims=True)
+    kw = dict(panel=inp["panel"], start=None, row_idx=row_idx, n_rows=n_rows, col_idx=col_idx, rf_adj=rf_adj, n_r=n_r,
+              hf_panel=inp["hf_panel"], hf_start=inp["hf_start"], m=m, w0=w0, n0=inp["n0"])
+    ref, rstat, _ = oracle.posterior_batch_c("conjugate", k, N, 5.0, **kw)
+    kernel_choice("0")
+    w_multi, s_multi, _ = native.posterior_batch("conjugate", k, N, 5.0, **kw)
+    kernel_choice("1")
+    w_wave, s_wave, _ = native.posterior_batch("conjugate", k, N, 5.0, **kw)
+    assert (s_wave == rstat).all() and (s_multi == rstat).all()
+    np.testing.assert_allclose(w_wave, ref, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(w_wave, w_multi, rtol=0, atol=1e-12)
+
+
+def test_wave_kernel_flags_a_singular_window(native, kernel_choice):
+    """A rank-deficient window (k > rows, Jeffreys) is flagged NOT_PD by the one-wave kernel too, never returned as numbers."""
+    k, N = 60, 30
+    inp = synthetic.make_kernel_inputs(k, N, 6, seed=3)
+    kernel_choice("1")
+    w, s, _ = _run(native, "jeffreys", k, N, inp)
+    assert (s != 0).all()

@@ -89,26 +89,42 @@ def check_kernel(name, lines):
     prog = parse(lines)
     labels = {p[1]: i for i, p in enumerate(prog) if p[0] == "label"}
     findings, n_asm = [], 0
+
+    def follow(j, sub, depth):
+        """Walk from instruction index j for as long as a result is pending (at most WAIT wait states, so this
+        terminates), taking both sides of every branch."""
+        while sub and j < len(prog):
+            q = prog[j]
+            j += 1
+            if q[0] == "label":
+                continue
+            _, tgt, ends = step(q, sub, findings, name)
+            sub = {r: v for r, v in sub.items() if v > 0}
+            if ends:
+                return
+            if tgt in labels and sub and depth < 8:
+                follow(labels[tgt], dict(sub), depth + 1)
+            if q[1].split()[0] == "s_branch":
+                return
+
     pending = {}
-    for i, p in enumerate(prog):            # layout order, results carried across every boundary (conservative)
+    for i, p in enumerate(prog):            # layout order; results are carried across fall-through boundaries
         if p[0] == "label":
             continue
-        is_asm, tgt, _ = step(p, pending, findings, name)
+        is_asm, tgt, ends = step(p, pending, findings, name)
         n_asm += is_asm
         pending = {r: v for r, v in pending.items() if v > 0}
-        if tgt in labels and pending:        # and along the branch, for as long as a result is pending
-            sub, j, n = dict(pending), labels[tgt], 0
-            while sub and j < len(prog) and n < 64:
-                q = prog[j]
-                j += 1
-                if q[0] == "label":
-                    continue
-                n += 1
-                _, _, ends = step(q, sub, findings, name)
-                sub = {r: v for r, v in sub.items() if v > 0}
-                if ends:
-                    break
-    return findings, n_asm
+        if tgt in labels and pending:        # and along every branch, for as long as a result is pending
+            follow(labels[tgt], dict(pending), 0)
+        if ends or p[1].split()[0] == "s_branch":
+            pending = {}                     # no fall-through behind an unconditional branch
+    seen, uniq = set(), []
+    for f in findings:
+        key = (f[1], tuple(f[2]))
+        if key not in seen:
+            seen.add(key)
+            uniq.append(f)
+    return uniq, n_asm
 
 
 def main(path):
@@ -138,5 +154,37 @@ def main(path):
     return rc
 
 
+SELFTEST = """_Z21posterior_wave_kernelILi7EEvv:
+\t;;#ASMSTART
+\ts_nop 1
+\tv_mfma_f64_16x16x4_f64 a[0:7], v[46:47], v[50:51], a[0:7]
+\t;;#ASMEND
+\t;;#ASMSTART
+\ts_nop 1
+\tv_mfma_f64_16x16x4_f64 a[0:7], v[46:47], v[50:51], a[0:7]
+\t;;#ASMEND
+\ts_nop 15
+\ts_cbranch_scc1 .LBB0_2
+\tv_accvgpr_read_b32 v3, a9
+\ts_nop 3
+\tv_accvgpr_read_b32 v3, a1
+\ts_endpgm
+.LBB0_2:
+\tv_accvgpr_read_b32 v2, a3
+\ts_endpgm
+.Lfunc_end0:
+"""
+
+
+def selftest():
+    """The accumulating MFMA and the read of a9 are legal; a3 (17 wait states, along the branch) is a finding, a1
+    (22 wait states) is not."""
+    lines = SELFTEST.split("\n")[1:]
+    findings, n = check_kernel("selftest", lines)
+    return n == 2 and [f[2] for f in findings] == [[3]]
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "--selftest":
+        sys.exit(0 if selftest() else 1)
     sys.exit(main(sys.argv[1]))
