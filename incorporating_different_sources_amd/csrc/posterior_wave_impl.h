@@ -318,7 +318,13 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
         }
         TP_MARK(1);
         // ---- phase B: Gram of the shifted / centred intraday rows
+        // the shift row is the window's FIRST row: shifted it is exactly zero and adds nothing to any sum, so the pass
+        // starts at row 1 (77 intraday rows: 19 k-steps instead of 20); the means of phase C still divide by all rows
+        const int hf_rows_all = hs.count;
+        if (shifted && !hs.ridx) { hs.first += 1; hs.count -= 1; }
+        else if (shifted) { hs.ridx += 1; hs.count -= 1; }
         wave_gram<NT, true, LEAN>(hs, cols, k, lane, shift, w0v, shifted, acc);
+        hs.count = hf_rows_all;
         TP_MARK(2);
         // ---- phase C: rank-one term of the centring (one-pass form); q0, c, scaling (ref:333, 415-418).  ONE pass over
         // the tiles, a tile row at a time: vector instructions cannot read AGPRs, every tile visits the VGPR half on its
@@ -413,34 +419,50 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
             }
         }
         TP_MARK(32);
+        // ONE table slot Q_L[b0]: [tile][2][64 lanes][2] doubles, two 16-byte reads per tile.  The reads run one group of
+        // tiles ahead of the additions.
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        constexpr int GRP = 7, NG = (C::NTILES + GRP - 1) / GRP;
+        const d2* pq = (const d2*)q + lane;
+        d2 qa[GRP][2], qb[GRP][2];
+        auto qload = [&](d2 (&v2)[GRP][2], auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            static_for<0, GRP>([&](auto ec) __attribute__((always_inline)) {
+                constexpr int e = decltype(ec)::value;
+                constexpr int t = g * GRP + e;
+                if constexpr (t < C::NTILES) {
+                    v2[e][0] = pq[(long long)t * 128];
+                    v2[e][1] = pq[(long long)t * 128 + 64];
+                }
+            });
+        };
+        auto qadd = [&](d2 (&v2)[GRP][2], auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            static_for<0, GRP>([&](auto ec) __attribute__((always_inline)) {
+                constexpr int e = decltype(ec)::value;
+                constexpr int t = g * GRP + e;
+                if constexpr (t < C::NTILES) {
+                    d4 x = acc[t];
+                    x[0] += v2[e][0][0]; x[1] += v2[e][0][1];
+                    x[2] += v2[e][1][0]; x[3] += v2[e][1][1];
+                    acc[t] = x;
+                    wave_pin1(acc[t]);
+                }
+            });
+        };
         wave_gram<NT, false, LEAN>(ds, cols, k, lane, none, none, false, acc);
         TP_MARK(33);
         if (LEAN && shared) {
-            // ONE table slot Q_L[b0]: [tile][2][64 lanes][2] doubles, two 16-byte reads per tile, 7 tiles in flight
-            typedef double d2 __attribute__((ext_vector_type(2)));
-            const d2* pq = (const d2*)q + lane;
-            constexpr int GRP = 7;
-            static_for<0, (C::NTILES + GRP - 1) / GRP>([&](auto gc) __attribute__((always_inline)) {
+            // (issuing the first group in front of the edge rows' loop was measured and dropped: the loop's counted
+            // vmcnt waits then also wait for the table reads - 0.648 vs 0.593 ms at configs[1])
+            qload(qa, ic<0>{});
+            static_for<0, NG>([&](auto gc) __attribute__((always_inline)) {
                 constexpr int g = decltype(gc)::value;
-                d2 v2[GRP][2];
-                static_for<0, GRP>([&](auto ec) __attribute__((always_inline)) {
-                    constexpr int t = g * GRP + decltype(ec)::value;
-                    if constexpr (t < C::NTILES) {
-                        v2[decltype(ec)::value][0] = pq[(long long)t * 128];
-                        v2[decltype(ec)::value][1] = pq[(long long)t * 128 + 64];
-                    }
-                });
-                static_for<0, GRP>([&](auto ec) __attribute__((always_inline)) {
-                    constexpr int e = decltype(ec)::value;
-                    constexpr int t = g * GRP + e;
-                    if constexpr (t < C::NTILES) {
-                        d4 x = acc[t];
-                        x[0] += v2[e][0][0]; x[1] += v2[e][0][1];
-                        x[2] += v2[e][1][0]; x[3] += v2[e][1][1];
-                        acc[t] = x;
-                        wave_pin1(acc[t]);
-                    }
-                });
+                if constexpr (g + 1 < NG) {
+                    if constexpr (g % 2 == 0) qload(qb, ic<g + 1>{}); else qload(qa, ic<g + 1>{});
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (g % 2 == 0) qadd(qa, gc); else qadd(qb, gc);
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -535,7 +557,7 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
 
     TP_MARK(4);
     // ---- phase F: blocked upper Cholesky S1 = R'R with the border column riding along (y = R^-T b)
-    bool bad = false;
+    double badacc = 0.0;
     static_for<0, NT>([&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
         if (j < NTB) {
@@ -551,22 +573,23 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
             const double* src = (lane < 16) ? (lds + C::OFF_DG) : (lds + C::OFF_IDT);
 #pragma unroll
             for (int i = 0; i < 16; ++i) a[i] = src[i * 16 + c16];
-            // (2) 16 pivots: multipliers by v_readlane, rsqrt (v_rsq_f64 + one cubic step) with look-ahead
+            // (2) 16 pivots: multipliers by v_readlane, rsqrt (v_rsq_f64 + one cubic step) with look-ahead.  Block rows in
+            // front of the last one have 16 live pivots at compile time (no selects).  A non-positive or NaN pivot makes
+            // its 1/sqrt an infinity or a NaN: 0 * rinv is accumulated per pivot (ONE instruction) and looked at once.
+            constexpr bool ALL16 = j < kI;
             double d0 = readlane_d(a[0], 0);
-            bad |= !(d0 > 0.0);
             double rinv = rsqrt_cubic(d0);
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
-                if (p < npiv) {
+                if (ALL16 || p < npiv) {
                     a[p] *= rinv;
+                    badacc = fma(0.0, rinv, badacc);
                     double rinv_next = 1.0;
                     if (p + 1 < 16) {
                         const double s1 = readlane_d(a[p], p + 1);
                         a[p + 1] = fma(-s1, a[p], a[p + 1]);
                         double dn = readlane_d(a[p + 1], p + 1);
-                        const bool live = p + 1 < npiv;
-                        bad |= live && !(dn > 0.0);
-                        dn = live ? dn : 1.0;
+                        if (!ALL16) dn = (p + 1 < npiv) ? dn : 1.0;
                         rinv_next = rsqrt_cubic(dn);
                     }
 #pragma unroll
@@ -680,7 +703,7 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
             }
         });
         const bool anybad = __any(nonfinite ? 1 : 0) != 0;
-        const bool notpd = __any(bad ? 1 : 0) != 0;
+        const bool notpd = __any((badacc != badacc) ? 1 : 0) != 0;
         if (lane == 0) {
             int st = TP_KSTATUS_OK;
             if (notpd) st = TP_KSTATUS_NOT_PD;
