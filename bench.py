@@ -43,6 +43,16 @@ def alg_flops_per_window(k, n_r, m, conj=True):
     return ((n_r + m) * k * (k + 1) + k ** 3 / 3 + 6 * k ** 2) if conj else (n_r * k * (k + 1) + k ** 3 / 3 + 5 * k ** 2)
 
 
+def register_tile_kernel(k):
+    """Which of the two register-tile kernels the library runs for k assets (csrc/posterior_fused.hip,
+    tp_use_wave_kernel): one wavefront per window up to 7 tiles per side, the multi-wave kernel above;
+    TP_WAVE_KERNEL=0/1 in the environment overrides it for A/B measurements."""
+    nt = (k + 1 + 15) // 16
+    env = os.environ.get("TP_WAVE_KERNEL", "")
+    wave = (int(env) != 0) if env else nt <= 7
+    return "posterior_wave_kernel (one wavefront per window)" if wave and nt <= 7 else "posterior_fused_kernel"
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -303,7 +313,7 @@ def worker(args):
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes)" if traffic else None,
-                         "kernel": ("posterior_fused_kernel" + (" (+ block_gram_kernel and tp_window_sums_kernel in front of it, every step)" if shared_blocks else ""))
+                         "kernel": (register_tile_kernel(k) + (" (+ block_gram_kernel and tp_window_sums_kernel in front of it, every step)" if shared_blocks else ""))
                                    if k <= 239 else "tiled pipeline (prior + prefix + gram + diag / TRSM / SYRK + solve)",
                          "kernel_ms": kernel_ms,
                          "alg_flops_per_window": alg_flops_per_window(k, n_r, m, conj),

@@ -16,7 +16,7 @@ import csv, glob, sys, collections
 acc = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "posterior_fused_kernel" in r["Kernel_Name"]:
+        if "posterior_fused_kernel" in r["Kernel_Name"] or "posterior_wave_kernel" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 print(sys.argv[2], {k: round(sum(v) / len(v) / 10000, 1) for k, v in sorted(acc.items())})
 PY

@@ -3,7 +3,7 @@
 # combined with tracing).  Usage on the GPU box: tools/pmc_passes.sh <outdir under gpurun_out> [kernel substring] [bench.py args]
 set -e
 OUT=${GRAFT_REPO_ROOT:-$PWD}/gpurun_out/${1:-pmc_stall}
-KERNEL=${2:-posterior_fused_kernel}
+KERNEL=${2:-posterior_wave_kernel}
 BENCH_ARGS=${3:---steps 2 --warmup 1}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
