@@ -22,6 +22,7 @@
 // after the Gram pass (t is the border column).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 
 #include "posterior_kernels.h"
@@ -770,6 +771,8 @@ void tp_tiled_geometry(int k, int* KP, int* NS, int* NSB) {
     *NS = ns; *KP = ns * SB; *NSB = (k + SB - 1) / SB;
 }
 
+#include "posterior_tiled_wave.h"
+
 // Whole pipeline for windows [a.w_first, a.w_first + a.w_count) (a.w_count <= ws capacity), on `stream`.
 size_t tp_tiled_slot_doubles(int k) {
     int KP, NS, NSB;
@@ -805,7 +808,11 @@ hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStre
         else if (nci <= 16) hipLaunchKernelGGL(tiled_prior_kernel<16>, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
         else hipLaunchKernelGGL(tiled_prior_kernel<32>, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
     }
-    if (lean) hipLaunchKernelGGL(tiled_gram_lean_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws);
+    // one wavefront per super-tile (posterior_tiled_wave.h) unless TP_TILED_WAVE=0 asks for the 4-wave kernels (A/B runs)
+    const char* tw = getenv("TP_TILED_WAVE");
+    if (!(tw && *tw && atoi(tw) == 0))
+        hipLaunchKernelGGL(tiled_gram_wave_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(64), 0, stream, a, ws);
+    else if (lean) hipLaunchKernelGGL(tiled_gram_lean_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws);
     else hipLaunchKernelGGL(tile64_kernel<MODE_GRAM>, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws, 0);
     if (!conj) hipLaunchKernelGGL(tiled_rank1_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws);
     hipLaunchKernelGGL(tiled_clear_kernel, dim3(G), dim3(NTHREADS), 0, stream, a, ws);

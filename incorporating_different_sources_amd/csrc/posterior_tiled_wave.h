@@ -1,0 +1,221 @@
+// posterior_tiled_wave.h - the Gram super-tile of the large-k path, ONE wavefront per 64 x 64 super-tile.
+// Included by posterior_tiled.hip (inside its anonymous namespace, after its helpers).
+//
+// The 4-wave Gram kernels (tile64_kernel<MODE_GRAM>, tiled_gram_lean_kernel) stage 16 rows at a time through LDS
+// and run 16 MFMAs per wave between two workgroup barriers: 64-67 % of the time the matrix pipe is busy
+// (tools/gram_loop_probe.hip: the loop shape itself tops out at 75 %).  Here a wave owns all 16 tiles of the
+// super-tile (128 accumulator registers, pinned to AGPRs) and loads the MFMA operands of a 4-row k-step straight
+// from the panels - lane (fq, fr) reads row 4s + fq, column 16 i + fr: eight 8-byte loads are the A and B operands of
+// all 16 MFMAs of the k-step.  No LDS, no barrier, three k-steps of loads in flight, two waves per SIMD.
+// Same loads, same arithmetic per element, same summation order as the 4-wave kernels: results are bit-identical.
+// The inline-assembly MFMAs follow the rules of posterior_wave_impl.h (s_nop 1 in front of every MFMA, a settle of
+// 24 wait states before any other use of an accumulator; tools/check_mfma_hazards.py checks the generated ISA).
+
+struct TRows {
+    const double* base;     // panel
+    long long ld;           // leading dimension (doubles)
+    const int* ridx;        // explicit rows of this window, or nullptr
+    long long first;        // first row (contiguous)
+    const double* rowc;     // per-row constant: border entry c sqrt(s) z_r (intraday) / risk-free adjustment (daily), or nullptr
+    int count;              // rows
+    int count0;             // two row ranges (shared daily sums): staged rows r >= count0 are panel rows first + r + jump
+    int jump;
+};
+
+__device__ __forceinline__ void tw_mfma_agpr(d4& c, double a, double b) {
+    asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void tw_pin1(d4& c0) { asm volatile("" : "+a"(c0)); }
+__device__ __forceinline__ void tw_settle8(d4& c0, d4& c1, d4& c2, d4& c3, d4& c4, d4& c5, d4& c6, d4& c7) {
+    asm volatile("s_nop 15\n\ts_nop 7" : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3), "+a"(c4), "+a"(c5), "+a"(c6), "+a"(c7));
+}
+
+// One pass over rows: acc(a, b) += rows[:, A group a]' rows[:, B group b], a, b = 0..3, 4 rows per k-step.
+//  HF:  intraday rows sqrt(s) (y - ybar), border column c sqrt(s) z_r (ref:317-333, 489)
+//  !HF: daily rows minus the risk-free adjustment, border column 1 (ref:57, 180, 222)
+template <bool DIAG, bool EDGE, bool HF>
+__device__ __forceinline__ void tw_gram_pass(const TRows& src, const long long (&co)[8], const double (&yb)[8],
+                                             const bool (&cval)[8], const bool (&cbord)[8], const double sqs, const int lane,
+                                             d4 (&acc)[16]) {
+    constexpr int NO = DIAG ? 4 : 8;            // operand registers per k-step (a diagonal super-tile: A = B)
+    const int fq = lane >> 4;
+    const int nks = (src.count + 3) >> 2;
+    const bool has_c = src.rowc != nullptr;
+    auto load = [&](double (&v)[NO], double& rc_, int ks) __attribute__((always_inline)) {
+        int r = 4 * ks + fq;
+        r = r < src.count ? r : src.count - 1;                      // rows past the end re-read the last row (masked below)
+        const int rr = r + (r >= src.count0 ? src.jump : 0);
+        const long long row = src.ridx ? (long long)src.ridx[rr] : src.first + rr;
+        const double* p = src.base + row * src.ld;
+#pragma unroll
+        for (int i = 0; i < NO; ++i) v[i] = p[co[i]];
+        rc_ = 0.0;
+        if (has_c) rc_ = src.rowc[rr];
+    };
+    auto step = [&](double (&v)[NO], double rc_, int ks, auto maskc) __attribute__((always_inline)) {
+        constexpr bool MASK = decltype(maskc)::value != 0;
+        if (HF) {
+#pragma unroll
+            for (int i = 0; i < NO; ++i) {
+                v[i] = sqs * (v[i] - yb[i]);                                       // sqrt(s) (y - ybar)
+                if (EDGE) v[i] = cval[i] ? v[i] : (cbord[i] ? rc_ : 0.0);          // border: c sqrt(s) z_r
+            }
+        } else {
+            if (has_c) {
+#pragma unroll
+                for (int i = 0; i < NO; ++i) v[i] -= rc_;                          // x - rf (ref:57)
+            }
+            if (EDGE) {
+#pragma unroll
+                for (int i = 0; i < NO; ++i) v[i] = cval[i] ? v[i] : (cbord[i] ? 1.0 : 0.0);   // border: ones -> t
+            }
+        }
+        if (MASK) {
+            const bool rv = 4 * ks + fq < src.count;
+#pragma unroll
+            for (int i = 0; i < NO; ++i) v[i] = rv ? v[i] : 0.0;
+        }
+        static_for_t<0, 4>([&](auto ac) __attribute__((always_inline)) {
+            constexpr int a = decltype(ac)::value;
+            static_for_t<0, 4>([&](auto bc) __attribute__((always_inline)) {
+                constexpr int b = decltype(bc)::value;
+                tw_mfma_agpr(acc[4 * a + b], v[a], v[DIAG ? b : 4 + b]);
+            });
+        });
+    };
+    if (nks <= 0) return;
+    double va[NO], vb[NO], vc[NO];
+    double ra = 0.0, rb = 0.0, rc = 0.0;
+    load(va, ra, 0);
+    load(vb, rb, 1);
+    static_for_t<0, 16>([&](auto tc) __attribute__((always_inline)) { tw_pin1(acc[decltype(tc)::value]); });
+    int ks = 0;
+#pragma nounroll
+    for (; 4 * (ks + 3) <= src.count; ks += 3) {
+        load(vc, rc, ks + 2);
+        step(va, ra, ks, std::integral_constant<int, 0>{});
+        load(va, ra, ks + 3);
+        step(vb, rb, ks + 1, std::integral_constant<int, 0>{});
+        load(vb, rb, ks + 4);
+        step(vc, rc, ks + 2, std::integral_constant<int, 0>{});
+    }
+    if (ks < nks) {
+        if (ks + 2 < nks) load(vc, rc, ks + 2);
+        step(va, ra, ks, std::integral_constant<int, 1>{});
+        if (ks + 1 < nks) step(vb, rb, ks + 1, std::integral_constant<int, 1>{});
+        if (ks + 2 < nks) step(vc, rc, ks + 2, std::integral_constant<int, 1>{});
+    }
+    tw_settle8(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
+    tw_settle8(acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]);
+}
+
+template <bool DIAG, bool EDGE>
+__device__ __forceinline__ void gram64_wave_body(const tp_kargs_t& A, const tp_tiled_ws_t& ws, const long long wl, const int SI,
+                                                 const int SJ) {
+    const int lane = threadIdx.x;
+    const int fr = lane & 15, fq = lane >> 4;
+    const long long w = A.w_first + wl;
+    const int k = A.k, KP = ws.KP;
+    double* M = ws.arena + wl * (long long)KP * KP;
+    const int* cols = A.col_idx ? A.col_idx + w * k : nullptr;
+    const bool conj = A.strategy == 0;
+    const int mm = conj ? (A.hf_count ? A.hf_count[w] : A.m) : 0;
+    const int nr = A.n_rows ? A.n_rows[w] : A.n_r;
+    const double sqs = conj ? ws.scal[wl * 8 + 1] : 0.0;
+    const double* ybar = ws.ybar + wl * KP;
+
+    long long co[8];
+    double yb[8];
+    bool cval[8], cbord[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int gc = 64 * ((i >> 2) ? SJ : SI) + fr + 16 * (i & 3);
+        cval[i] = !EDGE || gc < k;
+        cbord[i] = EDGE && gc == k;
+        const int gcl = cval[i] ? gc : k - 1;                      // padding columns re-read column k-1 (masked)
+        co[i] = cols ? (long long)cols[gcl] : (long long)gcl;
+        yb[i] = (conj && cval[i]) ? ybar[gcl] : 0.0;
+    }
+    d4 acc[16];
+    static_for_t<0, 16>([&](auto tc) __attribute__((always_inline)) {
+        acc[decltype(tc)::value] = d4{0.0, 0.0, 0.0, 0.0};
+        tw_pin1(acc[decltype(tc)::value]);
+    });
+
+    if (conj) {
+        TRows hs;
+        hs.base = A.hf_panel; hs.ld = A.hf_ld;
+        hs.ridx = A.hf_row_idx ? A.hf_row_idx + w * (long long)A.m : nullptr;
+        hs.first = A.hf_start ? A.hf_start[w] : 0;
+        hs.rowc = ws.zc + wl * (long long)A.m;
+        hs.count = mm; hs.count0 = 0x7fffffff; hs.jump = 0;
+        tw_gram_pass<DIAG, EDGE, true>(hs, co, yb, cval, cbord, sqs, lane, acc);
+    }
+    // daily rows; with the shared block-window sums only the rows in front of the first whole aligned block and behind
+    // the last one (see gram64_lean_body)
+    TRows ds;
+    ds.base = A.panel; ds.ld = A.panel_ld;
+    ds.ridx = A.row_idx ? A.row_idx + w * (long long)A.n_r : nullptr;
+    ds.first = A.start ? A.start[w] : 0;
+    ds.rowc = A.rf_adj ? A.rf_adj + w * (long long)A.n_r : nullptr;
+    ds.count = nr; ds.count0 = 0x7fffffff; ds.jump = 0;
+    const long long pb0 = (ds.first + CH - 1) / CH, pb1 = (ds.first + nr) / CH;
+    const int Lw = (int)(pb1 - pb0);
+    const int li = Lw == A.winsum_L[0] ? 0 : Lw == A.winsum_L[1] ? 1 : Lw == A.winsum_L[2] ? 2 : Lw == A.winsum_L[3] ? 3 : -1;
+    const bool shared = A.winsum != nullptr && !ds.ridx && Lw > 0 && li >= 0;
+    if (shared) {
+        ds.count0 = (int)(CH * pb0 - ds.first);
+        ds.jump = (int)(CH * pb1 - ds.first) - ds.count0;
+        ds.count = ds.count0 + (int)(ds.first + nr - CH * pb1);
+    }
+    tw_gram_pass<DIAG, EDGE, false>(ds, co, yb, cval, cbord, sqs, lane, acc);
+
+    // the table slot (tile row a of the super-tile at a time) and the store to the arena
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const long long ntile = (long long)ws.NS * (ws.NS + 1) / 2;
+    const d2* q = shared ? (const d2*)(A.winsum + (((long long)li * A.prefix_nblk + pb0) * ntile + pair_index(SI, SJ, ws.NS)) * (SB * SB)) + lane
+                         : nullptr;
+    static_for_t<0, 4>([&](auto ac) __attribute__((always_inline)) {
+        constexpr int a = decltype(ac)::value;
+        d2 v2[4][2];
+        if (shared) {
+            // [..][tile row a][16-column group b][2][64 lanes][2]: registers (0,1) and (2,3) of a lane are 16 contiguous bytes
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) v2[b][h] = q[a * 512 + (b * 2 + h) * 64];
+        }
+        static_for_t<0, 4>([&](auto bc) __attribute__((always_inline)) {
+            constexpr int b = decltype(bc)::value;
+            d4 x = acc[4 * a + b];
+            if (shared) {
+                x[0] += v2[b][0][0]; x[1] += v2[b][0][1];
+                x[2] += v2[b][1][0]; x[3] += v2[b][1][1];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) M[(long long)(64 * SI + 16 * a + fq + 4 * r) * KP + 64 * SJ + 16 * b + fr] = x[r];
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+__global__ void __launch_bounds__(64, 2) tiled_gram_wave_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws) {
+    long long wl;
+    int tile, SI, SJ;
+    if (!xcd_window_tile(ws.NS * (ws.NS + 1) / 2, A.w_count, wl, tile)) return;
+    pair_decode(tile, ws.NS, SI, SJ);
+    const bool edge = !(64 * SJ + 63 < A.k);                      // SI <= SJ: otherwise every column is a real asset
+    if (SI == SJ) {
+        if (edge) gram64_wave_body<true, true>(A, ws, wl, SI, SJ);
+        else gram64_wave_body<true, false>(A, ws, wl, SI, SJ);
+    } else {
+        if (edge) gram64_wave_body<false, true>(A, ws, wl, SI, SJ);
+        else gram64_wave_body<false, false>(A, ws, wl, SI, SJ);
+    }
+}
+
+// Measured and NOT kept (round 2): the factorisation's SYRK and TRSM super-tiles in the same one-wave form (eight loads
+// and 16 MFMAs per k-step, no staging at all).  They read the ARENA - 22 GB per 4,096 windows at k = 500, from HBM, each
+// tile a few times - and are bound by bytes in flight, not by the matrix pipe: two waves per SIMD with three k-steps of
+// loads each keep fewer bytes in flight than four 4-wave workgroups per CU, and the whole run got slower (k = 500:
+// 0.542 instead of 0.572 of the MFMA peak, k = 1000: 0.605 instead of 0.658; gpurun_out/r03j).
