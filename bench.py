@@ -45,12 +45,12 @@ def alg_flops_per_window(k, n_r, m, conj=True):
 
 def register_tile_kernel(k):
     """Which of the two register-tile kernels the library runs for k assets (csrc/posterior_fused.hip,
-    tp_use_wave_kernel): one wavefront per window up to 7 tiles per side, the multi-wave kernel above;
+    tp_use_wave_kernel): one wavefront per window up to 9 tiles per side, the multi-wave kernel above;
     TP_WAVE_KERNEL=0/1 in the environment overrides it for A/B measurements."""
     nt = (k + 1 + 15) // 16
     env = os.environ.get("TP_WAVE_KERNEL", "")
-    wave = (int(env) != 0) if env else nt <= 7
-    return "posterior_wave_kernel (one wavefront per window)" if wave and nt <= 7 else "posterior_fused_kernel"
+    wave = (int(env) != 0) if env else nt <= 9
+    return "posterior_wave_kernel (one wavefront per window)" if wave and nt <= 9 else "posterior_fused_kernel"
 
 
 def parse_args():

@@ -14,10 +14,11 @@ int tp_fused_max_assets(void) { return 16 * TP_MAX_NT - 1; }
 bool tp_use_wave_kernel(int nt) {
     const char* e = getenv("TP_WAVE_KERNEL");      // read per launch: a test process may flip it between runs
     if (e && *e) return atoi(e) != 0;
-    // measured on MI355X (tools/sweep_k.py, both kernels in one run, gpurun_out/r03f/sweep.log): one wave per window
-    // wins at every tile count it is built for: +10 % (k = 8) .. +55 % (k = 55), +24 % at k = 100.  Eight tiles
-    // (288 accumulator registers) no longer fit the AGPR half of the register file.
-    return nt >= 1 && nt <= 7;
+    // measured on MI355X (tools/sweep_k.py, both kernels in one run, gpurun_out/r03f/sweep.log and the round's later runs):
+    // one wave per window wins at every tile count it is built for: +10 % (k = 8) .. +55 % (k = 55), +24 % at k = 100,
+    // +22..31 % at 8 tiles (k = 112..127: four of the 36 tiles live in VGPRs), +15 % .. -2 % at 9 tiles (k = 128..143).
+    // Ten tiles per side (440 accumulator registers) no longer fit the register file next to the row pipeline.
+    return nt >= 1 && nt <= 9;
 }
 
 hipError_t tp_fused_launch(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info,

@@ -11,7 +11,7 @@
 
 // tile counts that also have the one-wave-per-window kernel (posterior_wave_nt.hip; the Makefile's WAVE_NTS)
 #define TP_WAVE_NT_MIN 1
-#define TP_WAVE_NT_MAX 7
+#define TP_WAVE_NT_MAX 9
 #if TP_NT >= TP_WAVE_NT_MIN && TP_NT <= TP_WAVE_NT_MAX
 hipError_t TP_CAT(tp_wave_launch_nt, TP_NT)(const tp_kargs_t&, int, hipStream_t, tp_launch_info_t*, bool);
 #define TP_WAVE_FN TP_CAT(tp_wave_launch_nt, TP_NT)

@@ -45,35 +45,51 @@ constexpr int wtile(int NT, int I, int J) { return I * NT - I * (I - 1) / 2 + (J
 // v_mfma_f64_16x16x4 result may be read by anything but the SrcC of the next MFMA on the same registers only 19
 // wait states after issue (what hipcc inserts behind the builtin).  Every pass over rows ends here; the asm
 // "modifies" every tile, so no later use of an accumulator can be scheduled in front of the wait.
+// Where a tile lives.  The first 32 tiles fill the AGPR half of the register file (256 registers); tile counts of 8 and
+// 9 per side (36 / 45 tiles) keep the rest in VGPRs - MFMA accumulators may be either.
+constexpr bool wave_tile_in_agpr(int t) { return t < 32; }
+
 // s_nop 1: a VGPR written by a vector instruction may be read as an MFMA operand two wait states later at the earliest
 // (hipcc puts the same s_nop in front of the builtin); the asm carries it because the compiler cannot see the hazard.
+template <int T>
 __device__ __forceinline__ void wave_mfma_agpr(d4& c, double a, double b) {
-    asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    if constexpr (wave_tile_in_agpr(T)) asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void wave_settle14(d4& c0, d4& c1, d4& c2, d4& c3, d4& c4, d4& c5, d4& c6, d4& c7, d4& c8, d4& c9,
                                               d4& c10, d4& c11, d4& c12, d4& c13) {
     asm volatile("s_nop 15\n\ts_nop 7" : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3), "+a"(c4), "+a"(c5), "+a"(c6), "+a"(c7), "+a"(c8),
                  "+a"(c9), "+a"(c10), "+a"(c11), "+a"(c12), "+a"(c13));
 }
-__device__ __forceinline__ void wave_settle1(d4& c0) { asm volatile("s_nop 15\n\ts_nop 7" : "+a"(c0)); }
+template <int T>
+__device__ __forceinline__ void wave_settle1(d4& c0) {
+    if constexpr (wave_tile_in_agpr(T)) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(c0));
+    else asm volatile("s_nop 15\n\ts_nop 7" : "+v"(c0));
+}
 // Entering a row loop: hand the loop-carried accumulators over as AGPR values (an empty asm that "modifies" them), so
 // that the loop's phi nodes become AGPR phis; otherwise the accumulators live in VGPRs across the back edge and are
 // copied into AGPRs for the asm MFMAs on every iteration.
-__device__ __forceinline__ void wave_pin1(d4& c0) { asm volatile("" : "+a"(c0)); }
+template <int T>
+__device__ __forceinline__ void wave_pin1(d4& c0) {
+    if constexpr (wave_tile_in_agpr(T)) asm volatile("" : "+a"(c0));
+    else asm volatile("" : "+v"(c0));
+}
 template <int NT>
 __device__ __forceinline__ void wave_pin(d4 (&acc)[WCfg<NT>::NTILES]) {
-    static_for<0, WCfg<NT>::NTILES>([&](auto tc) __attribute__((always_inline)) { wave_pin1(acc[decltype(tc)::value]); });
+    static_for<0, WCfg<NT>::NTILES>([&](auto tc) __attribute__((always_inline)) { wave_pin1<decltype(tc)::value>(acc[decltype(tc)::value]); });
 }
 template <int NT>
 __device__ __forceinline__ void wave_settle(d4 (&acc)[WCfg<NT>::NTILES]) {
     constexpr int NTL = WCfg<NT>::NTILES;
     static_for<0, (NTL + 13) / 14>([&](auto gc) __attribute__((always_inline)) {
         constexpr int b = 14 * decltype(gc)::value;
-        if constexpr (b + 14 <= NTL) {
+        if constexpr (b + 14 <= NTL && wave_tile_in_agpr(b + 13)) {
             wave_settle14(acc[b], acc[b + 1], acc[b + 2], acc[b + 3], acc[b + 4], acc[b + 5], acc[b + 6], acc[b + 7], acc[b + 8],
                           acc[b + 9], acc[b + 10], acc[b + 11], acc[b + 12], acc[b + 13]);
         } else {
-            static_for<b, NTL>([&](auto tc) __attribute__((always_inline)) { wave_settle1(acc[decltype(tc)::value]); });
+            static_for<b, (b + 14 < NTL ? b + 14 : NTL)>([&](auto tc) __attribute__((always_inline)) {
+                wave_settle1<decltype(tc)::value>(acc[decltype(tc)::value]);
+            });
         }
     });
 }
@@ -155,7 +171,7 @@ __device__ __forceinline__ void wave_gram(const WRows& src, const int* __restric
                 constexpr int t = wtile(NT, I, J);
                 // accumulators pinned to the AGPR half of the register file: left to itself the allocator moved the
                 // whole accumulator set between VGPRs and AGPRs inside this loop (497 v_accvgpr moves per 84 MFMAs)
-                wave_mfma_agpr(acc[t], v[I], v[J]);
+                wave_mfma_agpr<t>(acc[t], v[I], v[J]);
             });
         });
     };
@@ -383,7 +399,7 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
                     for (int r = 0; r < 4; ++r) x[r] *= (fq + 4 * r < kc) ? fcol : 0.0;
                 }
                 acc[t] = x;
-                wave_pin1(acc[t]);
+                wave_pin1<t>(acc[t]);
             });
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -446,7 +462,7 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
                     x[0] += v2[e][0][0]; x[1] += v2[e][0][1];
                     x[2] += v2[e][1][0]; x[3] += v2[e][1][1];
                     acc[t] = x;
-                    wave_pin1(acc[t]);
+                    wave_pin1<t>(acc[t]);
                 }
             });
         };
@@ -477,7 +493,7 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
 #pragma unroll
             for (int r = 0; r < 4; ++r) x[r] = (fq + 4 * r >= kc) ? 0.0 : x[r];
             acc[t] = x;
-            wave_pin1(acc[t]);
+            wave_pin1<t>(acc[t]);
         }
     });
     __builtin_amdgcn_sched_barrier(0);
@@ -518,7 +534,7 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
                     x[r] += on ? add - invN * (ti[r] * tj[J]) : 0.0;
                 }
                 acc[t] = x;
-                wave_pin1(acc[t]);
+                wave_pin1<t>(acc[t]);
             });
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -537,7 +553,7 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
                     acc[t][r] = (gi < k) ? x : 0.0;
                 }
             }
-            wave_pin1(acc[t]);
+            wave_pin1<t>(acc[t]);
         });
     }
     if (FULL && A.out_rhs != nullptr) {

@@ -37,12 +37,12 @@ def _run(native, strat, k, N, inp, **extra):
 
 @pytest.mark.parametrize("strat", ["conjugate", "jeffreys"])
 def test_every_universe_size_of_the_wave_kernel(native, kernel_choice, strat):
-    """EVERY k the one-wave kernel serves (1..111: seven tile counts, every position of the border column inside its
+    """EVERY k the one-wave kernel serves (1..143: nine tile counts, every position of the border column inside its
     tile, the two-pass sizes k+1 = 0 mod 16): against the oracle at the flat 1e-10 bound and against the multi-wave
     kernel (same arithmetic per element: agreement to a few ulps).  A per-instantiation compiler quirk (round 3: the
     corner read-out at k = 31 and 63) cannot hide between sampled sizes."""
     worst = 0.0
-    for k in range(1, 112):
+    for k in range(1, 144):
         N = max(2 * k + 10, 40) if strat == "jeffreys" else max(k + 30, 40)
         inp = synthetic.make_kernel_inputs(k, N, 9, seed=31000 + k)
         ref, rstat, _ = oracle.posterior_batch_c(strat, k, N, 5.0, **{kk: v for kk, v in dict(

@@ -10,7 +10,7 @@ their destination AGPRs.  This script proves its absence on the generated ISA:
     hipcc -O3 ... -S --cuda-device-only posterior_wave_nt.hip -o wave.s ;  check_mfma_hazards.py wave.s
 
 For every kernel whose name contains `posterior_wave_kernel` or `tiled_gram_wave_kernel` it walks the instruction stream (following branches
-for as long as a result is pending) and reports any instruction that reads or writes an AGPR of an asm MFMA's
+for as long as a result is pending) and reports any instruction that reads or writes a register of an asm MFMA's
 destination less than 19 wait states after that MFMA, other than an MFMA accumulating into exactly that tile.
 Exit code 1 on a finding.  Run by tests/test_cabi_symbols.py::test_wave_kernel_asm_hazards (CPU, cross-compile).
 """
@@ -18,16 +18,17 @@ import re
 import sys
 
 WAIT = 19
-REG = re.compile(r"\ba(\d+)\b|\ba\[(\d+):(\d+)\]")
+REG = re.compile(r"\b([av])(\d+)\b|\b([av])\[(\d+):(\d+)\]")
 
 
 def aregs(text):
+    """Vector registers named in `text`, as (file, index) pairs: accumulators may live in AGPRs or in VGPRs."""
     out = set()
     for m in REG.finditer(text):
         if m.group(1) is not None:
-            out.add(int(m.group(1)))
+            out.add((m.group(1), int(m.group(2))))
         else:
-            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+            out.update((m.group(3), i) for i in range(int(m.group(4)), int(m.group(5)) + 1))
     return out
 
 
@@ -181,7 +182,7 @@ def selftest():
     (22 wait states) is not."""
     lines = SELFTEST.split("\n")[1:]
     findings, n = check_kernel("selftest", lines)
-    return n == 2 and [f[2] for f in findings] == [[3]]
+    return n == 2 and [f[2] for f in findings] == [[("a", 3)]]
 
 
 if __name__ == "__main__":
