@@ -109,9 +109,13 @@ struct WRows {
 //  HF:   intraday rows, shifted by `shift` (the window's first row, or its column means), column k carries
 //        u_r = (y_r - shift).w0 and - when `ones` - column k+1 carries ones (one-pass centring, phase C)
 //  !HF:  daily rows minus the per-row risk-free adjustment, column k carries ones (t = X'1, ref:222)
+//  lazy_mask (HF): `shift` and `w0v` arrive as RAW loads (padding columns hold column k-1's values); they are zeroed
+//  beyond column k here, AFTER the first two k-steps' row loads have been issued - masking them at the call site made the
+//  wave wait for the shift row before it could ask for the first panel rows (two memory round trips in a row, and this
+//  wave has nothing else to run meanwhile)
 template <int NT, bool HF, bool LEAN>
 __device__ __forceinline__ void wave_gram(const WRows& src, const int* __restrict__ cols, int k, int lane,
-                                          const double (&shift)[NT], const double (&w0v)[NT], bool ones,
+                                          double (&shift)[NT], double (&w0v)[NT], bool ones, bool lazy_mask,
                                           d4 (&acc)[WCfg<NT>::NTILES]) {
     constexpr int kI = NT - 1;
     const int fr = lane & 15, fq = lane >> 4;
@@ -183,6 +187,15 @@ __device__ __forceinline__ void wave_gram(const WRows& src, const int* __restric
     double sa = 0.0, sb = 0.0, sc = 0.0;
     load(va, sa, 0);
     load(vb, sb, 1);
+    if (HF && lazy_mask) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const bool cv = 16 * i + fr < k;
+            shift[i] = cv ? shift[i] : 0.0;
+            w0v[i] = cv ? w0v[i] : 0.0;
+        }
+    }
     wave_pin<NT>(acc);
     int ks = 0;
 #pragma nounroll
@@ -301,11 +314,13 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
                 const int cl = c < k ? c : k - 1;
                 const double sv = p0[cols ? cols[cl] : cl];
                 const double wv = A.w0[w * k + cl];
-                shift[i] = (c < k) ? sv : 0.0;
-                w0v[i] = (c < k) ? wv : 0.0;
+                shift[i] = sv;               // raw: zeroed beyond column k inside wave_gram (lazy_mask) or just below
+                w0v[i] = wv;
             }
         }
         if (!shifted) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) w0v[i] = (16 * i + fr < k) ? w0v[i] : 0.0;
             // two-pass form: column means first (every lane group sums its rows, the four groups meet by shuffles)
             double cs[NT];
 #pragma unroll
@@ -339,7 +354,7 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
         const int hf_rows_all = hs.count;
         if (shifted && !hs.ridx) { hs.first += 1; hs.count -= 1; }
         else if (shifted) { hs.ridx += 1; hs.count -= 1; }
-        wave_gram<NT, true, LEAN>(hs, cols, k, lane, shift, w0v, shifted, acc);
+        wave_gram<NT, true, LEAN>(hs, cols, k, lane, shift, w0v, shifted, shifted, acc);
         hs.count = hf_rows_all;
         TP_MARK(2);
         // ---- phase C: rank-one term of the centring (one-pass form); q0, c, scaling (ref:333, 415-418).  ONE pass over
@@ -416,7 +431,7 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
         ds.sub_row = A.rf_adj ? A.rf_adj + w * (long long)A.n_r : nullptr;
         ds.count = A.n_rows ? A.n_rows[w] : A.n_r;
         ds.count0 = 0x7fffffff; ds.jump = 0;
-        const double none[NT] = {};
+        double none[NT] = {};
         bool shared = false;
         const double* q = nullptr;
         if constexpr (LEAN) {
@@ -466,7 +481,7 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
                 }
             });
         };
-        wave_gram<NT, false, LEAN>(ds, cols, k, lane, none, none, false, acc);
+        wave_gram<NT, false, LEAN>(ds, cols, k, lane, none, none, false, false, acc);
         TP_MARK(33);
         if (LEAN && shared) {
             // (issuing the first group in front of the edge rows' loop was measured and dropped: the loop's counted
