@@ -7,7 +7,8 @@
 // super-tile (128 accumulator registers, pinned to AGPRs) and loads the MFMA operands of a 4-row k-step straight
 // from the panels - lane (fq, fr) reads row 4s + fq, column 16 i + fr: eight 8-byte loads are the A and B operands of
 // all 16 MFMAs of the k-step.  No LDS, no barrier, three k-steps of loads in flight, two waves per SIMD.
-// Same loads, same arithmetic per element, same summation order as the 4-wave kernels: results are bit-identical.
+// Same loads, same arithmetic per element, same summation order as the 4-wave kernels: results are bit-identical
+// (the never-read tiles below the diagonal of a diagonal super-tile are left zero instead of being computed).
 // The inline-assembly MFMAs follow the rules of posterior_wave_impl.h (s_nop 1 in front of every MFMA, a settle of
 // 24 wait states before any other use of an accumulator; tools/check_mfma_hazards.py checks the generated ISA).
 
@@ -79,7 +80,9 @@ __device__ __forceinline__ void tw_gram_pass(const TRows& src, const long long (
             constexpr int a = decltype(ac)::value;
             static_for_t<0, 4>([&](auto bc) __attribute__((always_inline)) {
                 constexpr int b = decltype(bc)::value;
-                tw_mfma_agpr(acc[4 * a + b], v[a], v[DIAG ? b : 4 + b]);
+                // a diagonal super-tile: the tiles below its diagonal are never read (the diagonal-block kernel and the
+                // left-looking update use column >= row only) - 10 MFMAs per k-step instead of 16
+                if constexpr (!DIAG || a <= b) tw_mfma_agpr(acc[4 * a + b], v[a], v[DIAG ? b : 4 + b]);
             });
         });
     };
@@ -187,8 +190,8 @@ __device__ __forceinline__ void gram64_wave_body(const tp_kargs_t& A, const tp_t
         }
         static_for_t<0, 4>([&](auto bc) __attribute__((always_inline)) {
             constexpr int b = decltype(bc)::value;
-            d4 x = acc[4 * a + b];
-            if (shared) {
+            d4 x = acc[4 * a + b];               // (below the diagonal of a diagonal super-tile: the zeros it started with)
+            if (shared && (!DIAG || a <= b)) {
                 x[0] += v2[b][0][0]; x[1] += v2[b][0][1];
                 x[2] += v2[b][1][0]; x[3] += v2[b][1][1];
             }
