@@ -822,7 +822,9 @@ hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStre
     for (int j = 0; j < NSB; ++j) {
         const int T = NS - 1 - j;
         if (j > 0) hipLaunchKernelGGL(tile64_kernel<MODE_SYRK>, xcd_grid(T + 1, G), dim3(NTHREADS), 0, stream, a, ws, j);
-        hipLaunchKernelGGL(tiled_diag_kernel, dim3(G), dim3(NTHREADS), 0, stream, a, ws, j);
+        // the diagonal block by one wavefront per window (posterior_tiled_wave.h) unless TP_TILED_WAVE=0
+        if (!(tw && *tw && atoi(tw) == 0)) hipLaunchKernelGGL(tiled_diag_wave_kernel, dim3(G), dim3(64), 0, stream, a, ws, j);
+        else hipLaunchKernelGGL(tiled_diag_kernel, dim3(G), dim3(NTHREADS), 0, stream, a, ws, j);
         if (T > 0) hipLaunchKernelGGL(tile64_kernel<MODE_TRSM>, xcd_grid(T, G), dim3(NTHREADS), 0, stream, a, ws, j);
     }
     const size_t smem = sizeof(double) * (size_t)(ws.KP + SB);

@@ -222,3 +222,176 @@ __global__ void __launch_bounds__(64, 2) tiled_gram_wave_kernel(const tp_kargs_t
 // tile a few times - and are bound by bytes in flight, not by the matrix pipe: two waves per SIMD with three k-steps of
 // loads each keep fewer bytes in flight than four 4-wave workgroups per CU, and the whole run got slower (k = 500:
 // 0.542 instead of 0.572 of the MFMA peak, k = 1000: 0.605 instead of 0.658; gpurun_out/r03j).
+
+// ---- the 64 x 64 diagonal block by ONE wavefront ------------------------------------------------------------------
+// tiled_diag_kernel factorises the block with 4 waves and a workgroup barrier per pivot (64 of them): 229 us per block
+// step for 4,096 windows at k = 500, 10 % of the run.  Here the block is 4 x 4 MFMA tiles in ONE wave's registers and is
+// factorised exactly like phase F of the one-wave register-tile kernel (posterior_wave_impl.h): per 16-row tile row the
+// diagonal tile goes through LDS to one column per lane, 16 pivots by v_readlane eliminate it together with 16 identity
+// columns (M_a = R_aa^-T), the tile row becomes R_aB = M_a A_aB and the trailing tiles A_IB -= R_aI' R_aB, all by MFMA with
+// operands from the accumulators.  The 64 identity columns of the block ride along as 4 more tile columns: they come out
+// as Y = R_jj^-T, whose transpose is the R_jj^-1 the TRSM and solve kernels read - no inverse pass.
+__device__ __forceinline__ double tw_readlane_d(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+// 1/sqrt(d): v_rsq_f64 seed + one third-order step (see posterior_fused_impl.h, rsqrt_cubic)
+__device__ __forceinline__ double tw_rsqrt_cubic(double d) {
+    const double y = __builtin_amdgcn_rsq(d);
+    const double e = fma(-(d * y), y, 1.0);
+    const double u = fma(e, 0.375, 0.5);
+    return fma(y * e, u, y);
+}
+constexpr int tw_ta(int a, int b) { return a * 4 - a * (a - 1) / 2 + (b - a); }       // A tile (a, b), a <= b: 0..9
+constexpr int tw_ty(int b, int a) { return 10 + b * (b + 1) / 2 + a; }                 // Y tile (b, a), a <= b: 10..19
+
+__global__ void __launch_bounds__(64, 1) tiled_diag_wave_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws, const int j) {
+    constexpr int MLD = 17;
+    __shared__ __attribute__((aligned(16))) double lds[256 + 256 + 16 * MLD];          // diagonal tile | identity | M_a
+    double* DG = lds;
+    double* IDT = lds + 256;
+    double* MB = lds + 512;
+    const int lane = threadIdx.x;
+    const int fr = lane & 15, fq = lane >> 4;
+    const long long wl = blockIdx.x;
+    const int k = A.k, KP = ws.KP;
+    double* M = ws.arena + wl * (long long)KP * KP;
+    double* blk = M + (long long)(64 * j) * KP + 64 * j;
+    const int npiv = (k - 64 * j < SB) ? (k - 64 * j) : SB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = lane + 64 * i;
+        IDT[e] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
+    }
+    d4 acc[20];
+    static_for_t<0, 4>([&](auto ac) __attribute__((always_inline)) {
+        constexpr int a = decltype(ac)::value;
+        static_for_t<a, 4>([&](auto bc) __attribute__((always_inline)) {
+            constexpr int b = decltype(bc)::value;
+            d4 x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = blk[(long long)(16 * a + fq + 4 * r) * KP + 16 * b + fr];
+            acc[tw_ta(a, b)] = x;
+        });
+        static_for_t<0, a + 1>([&](auto cc) __attribute__((always_inline)) {
+            constexpr int c = decltype(cc)::value;
+            d4 x = d4{0.0, 0.0, 0.0, 0.0};
+            if (c == a) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = (fq + 4 * r == fr) ? 1.0 : 0.0;
+            }
+            acc[tw_ty(a, c)] = x;
+        });
+    });
+    double badacc = 0.0;
+    static_for_t<0, 4>([&](auto ac) __attribute__((always_inline)) {
+        constexpr int a = decltype(ac)::value;
+        const int np = npiv - 16 * a < 16 ? npiv - 16 * a : 16;      // pivots of this tile row (uniform)
+        if (np > 0) {
+            // (1) diagonal tile -> LDS (row-major) -> one column per lane; lanes 16-31 take the identity's columns
+#pragma unroll
+            for (int r = 0; r < 4; ++r) DG[(fq + 4 * r) * 16 + fr] = acc[tw_ta(a, a)][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int c16 = lane & 15;
+            double e[16];
+            const double* src = (lane < 16) ? DG : IDT;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) e[i] = src[i * 16 + c16];
+            // (2) the pivots (as in posterior_wave_impl.h, phase F)
+            double rinv = tw_rsqrt_cubic(tw_readlane_d(e[0], 0));
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                if (p < np) {
+                    e[p] *= rinv;
+                    badacc = fma(0.0, rinv, badacc);              // a non-positive or NaN pivot: rinv is an infinity or a NaN
+                    double rinv_next = 1.0;
+                    if (p + 1 < 16) {
+                        const double s1 = tw_readlane_d(e[p], p + 1);
+                        e[p + 1] = fma(-s1, e[p], e[p + 1]);
+                        double dn = tw_readlane_d(e[p + 1], p + 1);
+                        dn = (p + 1 < np) ? dn : 1.0;
+                        rinv_next = tw_rsqrt_cubic(dn);
+                    }
+#pragma unroll
+                    for (int i = p + 2; i < 16; ++i) {
+                        const double sI = tw_readlane_d(e[p], i);
+                        e[i] = fma(-sI, e[p], e[i]);
+                    }
+                    rinv = rinv_next;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // M_a = R_aa^-T; rows past the last pivot (the border row, padding) stay identity rows
+            if (lane >= 16 && lane < 32) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) MB[i * MLD + c16] = (i < np) ? e[i] : ((i == c16) ? 1.0 : 0.0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // (3) tile row a: R_aB = M_a A_aB (B >= a) and Y_aC = M_a Y_aC (C <= a)
+            double mop[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mop[r] = MB[fr * MLD + 4 * r + fq];          // M[fr][4r + fq]
+            auto trsm = [&](d4& t) __attribute__((always_inline)) {
+                d4 rj = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rj = __builtin_amdgcn_mfma_f64_16x16x4f64(mop[r], t[r], rj, 0, 0, 0);
+                t = rj;
+            };
+            static_for_t<a, 4>([&](auto bc) __attribute__((always_inline)) { trsm(acc[tw_ta(a, decltype(bc)::value)]); });
+            static_for_t<0, a + 1>([&](auto cc) __attribute__((always_inline)) { trsm(acc[tw_ty(a, decltype(cc)::value)]); });
+            // (4) trailing tiles: A_IB -= R_aI' R_aB, Y_IC -= R_aI' Y_aC
+            static_for_t<a + 1, 4>([&](auto Ic) __attribute__((always_inline)) {
+                constexpr int I = decltype(Ic)::value;
+                static_for_t<I, 4>([&](auto bc) __attribute__((always_inline)) {
+                    constexpr int b = decltype(bc)::value;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[tw_ta(I, b)] = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[tw_ta(a, I)][r], acc[tw_ta(a, b)][r], acc[tw_ta(I, b)], 0, 0, 1);
+                });
+                static_for_t<0, a + 1>([&](auto cc) __attribute__((always_inline)) {
+                    constexpr int c = decltype(cc)::value;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[tw_ty(I, c)] = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[tw_ta(a, I)][r], acc[tw_ty(a, c)][r], acc[tw_ty(I, c)], 0, 0, 1);
+                });
+            });
+            __builtin_amdgcn_wave_barrier();
+        }
+    });
+    // factored rows back to the arena (upper part; the border column of the last block is y): rows past the last pivot untouched
+    static_for_t<0, 4>([&](auto ac) __attribute__((always_inline)) {
+        constexpr int a = decltype(ac)::value;
+        static_for_t<a, 4>([&](auto bc) __attribute__((always_inline)) {
+            constexpr int b = decltype(bc)::value;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * a + fq + 4 * r, c = 16 * b + fr;
+                if (i < npiv && c >= i) blk[(long long)i * KP + c] = acc[tw_ta(a, b)][r];
+            }
+        });
+    });
+    // row-major R_jj^-1 = Y': (R^-1)[i][c] = Y[c][i]; identity in the rows / columns past the last pivot, zero below the diagonal
+    double* rinvp = ws.rinv + (wl * ws.NSB + j) * (long long)(SB * SB);
+    static_for_t<0, 4>([&](auto bc) __attribute__((always_inline)) {
+        constexpr int b = decltype(bc)::value;
+        static_for_t<0, 4>([&](auto ac) __attribute__((always_inline)) {
+            constexpr int a = decltype(ac)::value;
+            if constexpr (a <= b) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int yr = 16 * b + fq + 4 * r, yc = 16 * a + fr;           // Y[yr][yc] -> (R^-1)[yc][yr]
+                    const double v = (yr < npiv) ? acc[tw_ty(b, a)][r] : ((yr == yc) ? 1.0 : 0.0);
+                    rinvp[yc * SB + yr] = v;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rinvp[(16 * a + fq + 4 * r) * SB + 16 * b + fr] = 0.0;   // (R^-1) tile (a, b), a > b
+            }
+        });
+    });
+    const bool bad = __any((badacc != badacc) ? 1 : 0) != 0;
+    if (lane == 0 && bad) ws.flags[wl] = 1;
+}
