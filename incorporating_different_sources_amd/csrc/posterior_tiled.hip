@@ -36,7 +36,7 @@ constexpr int CH = 16;                 // staged rows per chunk
 constexpr int LDX = 2 * SB + 16;       // LDS row stride of a staged chunk (A cols | B cols), 144 = 16 mod 32
 constexpr int NTHREADS = 256;
 
-enum { MODE_GRAM = 0, MODE_TRSM = 1, MODE_SYRK = 2 };
+enum { MODE_GRAM = 0, MODE_TRSM = 1, MODE_SYRK = 2, MODE_SYRK_DIAG = 3 };   // SYRK_DIAG: the update of tile (j, j) alone
 
 template <int N>
 __device__ __forceinline__ double dpp_row_ror(double v) {
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
     const int T = NS - 1 - j;                                  // TRSM: block columns to the right of step j
     long long wl;
     int tile;
-    if (!xcd_window_tile(MODE == MODE_GRAM ? NS * (NS + 1) / 2 : (MODE == MODE_TRSM ? T : T + 1), A.w_count, wl, tile))
+    if (!xcd_window_tile(MODE == MODE_GRAM ? NS * (NS + 1) / 2 : (MODE == MODE_TRSM ? T : (MODE == MODE_SYRK_DIAG ? 1 : T + 1)), A.w_count, wl, tile))
         return;
     const long long w = A.w_first + wl;
     double* M = ws.arena + wl * (long long)KP * KP;
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
     d4 acc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
-    if (MODE == MODE_SYRK) {           // C - R'R: start from C
+    if (MODE == MODE_SYRK || MODE == MODE_SYRK_DIAG) {           // C - R'R: start from C
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
     const bool interior = MODE == MODE_GRAM && 64 * SJ + 63 < k;     // SI <= SJ: both column groups are real assets
     // GRAM rows: [intraday rows, padded to whole chunks][daily rows]; a chunk is purely one kind
     const int hchunks = (mm + CH - 1) / CH;
-    const int nchunks = (MODE == MODE_GRAM) ? hchunks + (nr + CH - 1) / CH : (MODE == MODE_SYRK ? (SB / CH) * j : SB / CH);
+    const int nchunks = (MODE == MODE_GRAM) ? hchunks + (nr + CH - 1) / CH : ((MODE == MODE_SYRK || MODE == MODE_SYRK_DIAG) ? (SB / CH) * j : SB / CH);
     double v[8];
     double rowc = 0.0;      // per-row constant: border entry (intraday) / risk-free adjustment (daily)
     bool rowv = false;
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
             }
         } else {
             // TRSM: the 64 rows of block row j; SYRK: the rows of block rows 0 .. j-1, one after the other
-            const int r = (MODE == MODE_SYRK) ? ch * CH + srow : 64 * j + ch * CH + srow;
+            const int r = (MODE == MODE_SYRK || MODE == MODE_SYRK_DIAG) ? ch * CH + srow : 64 * j + ch * CH + srow;
             const double* rowA = (MODE == MODE_TRSM) ? rinv + (ch * CH + srow) * SB : M + (long long)r * KP;
             const double* rowB = M + (long long)r * KP;
 #pragma unroll
@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(NTHREADS) tile64_kernel(const tp_kargs_t A, co
 #pragma unroll
             for (int b = 0; b < 4; ++b)      // SYRK: acc -= a'b through the negate bit of the f64 MFMA (BLGP bit 0)
                 acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, lb[4 * s4 * LDX + 64 + 16 * b], acc[b], 0, 0,
-                                                              MODE == MODE_SYRK ? 1 : 0);
+                                                              (MODE == MODE_SYRK || MODE == MODE_SYRK_DIAG) ? 1 : 0);
         }
         if (more) store(nxt, ch + 1);
         __syncthreads();
@@ -771,6 +771,112 @@ void tp_tiled_geometry(int k, int* KP, int* NS, int* NSB) {
     *NS = ns; *KP = ns * SB; *NSB = (k + SB - 1) / SB;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Block step j, the tiles (j, J), J > j, in ONE kernel: the left-looking update A_jJ -= sum_{q<j} R_qj' R_qJ and, on the tile
+// still in registers, R_jJ = R_jj^-T A_jJ.  As two kernels (tile64_kernel<MODE_SYRK> then <MODE_TRSM>) every such tile was
+// written to the arena and read back in between - the TRSM launch moved 1 GB per block step at k = 500 and ran at the HBM
+// rate (9.5 % of the run).  Runs after tiled_diag*_kernel(j), which needs the updated tile (j, j) first (its own launch).
+// Staging as in tile64_kernel; in the TRSM part the B half of chunk c (rows 16c..16c+15 of the tile) comes from the
+// accumulators of wave c instead of from memory.
+__global__ void __launch_bounds__(NTHREADS) tile64_syrk_trsm_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws, const int j) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * CH * LDX];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int KP = ws.KP, NS = ws.NS;
+    const int T = NS - 1 - j;
+    long long wl;
+    int tile;
+    if (!xcd_window_tile(T, A.w_count, wl, tile)) return;
+    double* M = ws.arena + wl * (long long)KP * KP;
+    const int SI = j, SJ = j + 1 + tile;
+    const double* rinv = ws.rinv + (wl * ws.NSB + j) * (long long)(SB * SB);
+    d4 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[b][r] = M[(long long)(64 * SI + 16 * wv + fq + 4 * r) * KP + 64 * SJ + 16 * b + fr];
+    const int srow = tid >> 4, cb = tid & 15;
+    double v[8];
+    // ---- left-looking update: rows of block rows 0 .. j-1, A half = columns of super-tile j, B half = columns of super-tile J
+    const int nchunks = (SB / CH) * j;
+    auto load = [&](int ch) __attribute__((always_inline)) {
+        const double* row = M + (long long)(ch * CH + srow) * KP;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = row[64 * SI + cb + 16 * i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[4 + i] = row[64 * SJ + cb + 16 * i];
+    };
+    auto store = [&](double* buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) buf[srow * LDX + 64 * (i >> 2) + cb + 16 * (i & 3)] = v[i];
+    };
+    if (nchunks > 0) { load(0); store(lds); }
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        double* cur = lds + (ch & 1) * CH * LDX;
+        double* nxt = lds + ((ch + 1) & 1) * CH * LDX;
+        const bool more = ch + 1 < nchunks;
+        if (more) load(ch + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const double* lb = cur + fq * LDX + fr;
+#pragma unroll
+        for (int s4 = 0; s4 < CH / 4; ++s4) {
+            const double a = lb[4 * s4 * LDX + 16 * wv];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, lb[4 * s4 * LDX + 64 + 16 * b], acc[b], 0, 0, 1);
+        }
+        if (more) store(nxt);
+        __syncthreads();
+    }
+    // ---- R_jJ = R_jj^-T A_jJ: chunk c = rows 16c..16c+15 of R_jj^-1 (A half, from memory) and of the tile (B half, wave c's registers)
+    d4 res[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) res[b] = d4{0.0, 0.0, 0.0, 0.0};
+    auto load_t = [&](int c) __attribute__((always_inline)) {
+        const double* row = rinv + (c * CH + srow) * SB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = row[cb + 16 * i];
+    };
+    auto store_t = [&](double* buf, int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) buf[srow * LDX + cb + 16 * i] = v[i];
+        if (wv == c) {             // this wave's 16 rows of the tile, in the layout of the staged rows
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) buf[(fq + 4 * r) * LDX + 64 + 16 * b + fr] = acc[b][r];
+        }
+    };
+    load_t(0); store_t(lds, 0);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < SB / CH; ++c) {
+        double* cur = lds + (c & 1) * CH * LDX;
+        double* nxt = lds + ((c + 1) & 1) * CH * LDX;
+        const bool more = c + 1 < SB / CH;
+        if (more) load_t(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const double* lb = cur + fq * LDX + fr;
+#pragma unroll
+        for (int s4 = 0; s4 < CH / 4; ++s4) {
+            const double a = lb[4 * s4 * LDX + 16 * wv];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                res[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, lb[4 * s4 * LDX + 64 + 16 * b], res[b], 0, 0, 0);
+        }
+        if (more) store_t(nxt, c + 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            M[(long long)(64 * SI + 16 * wv + fq + 4 * r) * KP + 64 * SJ + 16 * b + fr] = res[b][r];
+}
+
 #include "posterior_tiled_wave.h"
 
 // Whole pipeline for windows [a.w_first, a.w_first + a.w_count) (a.w_count <= ws capacity), on `stream`.
@@ -810,6 +916,7 @@ hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStre
     }
     // one wavefront per super-tile (posterior_tiled_wave.h) unless TP_TILED_WAVE=0 asks for the 4-wave kernels (A/B runs)
     const char* tw = getenv("TP_TILED_WAVE");
+    const char* tf = getenv("TP_TILED_FUSE");
     if (!(tw && *tw && atoi(tw) == 0))
         hipLaunchKernelGGL(tiled_gram_wave_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(64), 0, stream, a, ws);
     else if (lean) hipLaunchKernelGGL(tiled_gram_lean_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws);
@@ -821,11 +928,20 @@ hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStre
     // diagonal block is factorised and the rest of the row is solved.
     for (int j = 0; j < NSB; ++j) {
         const int T = NS - 1 - j;
-        if (j > 0) hipLaunchKernelGGL(tile64_kernel<MODE_SYRK>, xcd_grid(T + 1, G), dim3(NTHREADS), 0, stream, a, ws, j);
+        // measured (TP_TILED_FUSE = 0 / 1 runs of round 2): fused +1.6..2 % at k = 500 (8 super-tiles per side), -1.5 % at
+        // k = 1000 (16: the fused kernel's longer workgroups balance worse over the many tiles of a block row)
+        const bool fused = (tf && *tf) ? atoi(tf) != 0 : NS <= 8;
+        // the left-looking update: of the diagonal tile only (the rest of the row takes it together with its solve below), or of
+        // the whole row (TP_TILED_FUSE=0: the three-kernel form, for A/B runs)
+        if (j > 0 && fused) hipLaunchKernelGGL(tile64_kernel<MODE_SYRK_DIAG>, xcd_grid(1, G), dim3(NTHREADS), 0, stream, a, ws, j);
+        else if (j > 0) hipLaunchKernelGGL(tile64_kernel<MODE_SYRK>, xcd_grid(T + 1, G), dim3(NTHREADS), 0, stream, a, ws, j);
         // the diagonal block by one wavefront per window (posterior_tiled_wave.h) unless TP_TILED_WAVE=0
         if (!(tw && *tw && atoi(tw) == 0)) hipLaunchKernelGGL(tiled_diag_wave_kernel, dim3(G), dim3(64), 0, stream, a, ws, j);
         else hipLaunchKernelGGL(tiled_diag_kernel, dim3(G), dim3(NTHREADS), 0, stream, a, ws, j);
-        if (T > 0) hipLaunchKernelGGL(tile64_kernel<MODE_TRSM>, xcd_grid(T, G), dim3(NTHREADS), 0, stream, a, ws, j);
+        if (T > 0) {
+            if (fused) hipLaunchKernelGGL(tile64_syrk_trsm_kernel, xcd_grid(T, G), dim3(NTHREADS), 0, stream, a, ws, j);
+            else hipLaunchKernelGGL(tile64_kernel<MODE_TRSM>, xcd_grid(T, G), dim3(NTHREADS), 0, stream, a, ws, j);
+        }
     }
     const size_t smem = sizeof(double) * (size_t)(ws.KP + SB);
     hipLaunchKernelGGL(tiled_solve_kernel, dim3(G), dim3(NTHREADS), smem, stream, a, ws);
