@@ -933,10 +933,14 @@ hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStre
         const bool fused = (tf && *tf) ? atoi(tf) != 0 : NS <= 8;
         // the left-looking update: of the diagonal tile only (the rest of the row takes it together with its solve below), or of
         // the whole row (TP_TILED_FUSE=0: the three-kernel form, for A/B runs)
-        if (j > 0 && fused) hipLaunchKernelGGL(tile64_kernel<MODE_SYRK_DIAG>, xcd_grid(1, G), dim3(NTHREADS), 0, stream, a, ws, j);
-        else if (j > 0) hipLaunchKernelGGL(tile64_kernel<MODE_SYRK>, xcd_grid(T + 1, G), dim3(NTHREADS), 0, stream, a, ws, j);
+        const bool wave_diag = !(tw && *tw && atoi(tw) == 0);
+        // fused: the diagonal tile takes its update inside the one-wave diagonal-block kernel (or in a launch of its own in
+        // front of the 4-wave one), the rest of the row together with its solve below
+        if (j > 0 && fused && !wave_diag) hipLaunchKernelGGL(tile64_kernel<MODE_SYRK_DIAG>, xcd_grid(1, G), dim3(NTHREADS), 0, stream, a, ws, j);
+        else if (j > 0 && !fused) hipLaunchKernelGGL(tile64_kernel<MODE_SYRK>, xcd_grid(T + 1, G), dim3(NTHREADS), 0, stream, a, ws, j);
         // the diagonal block by one wavefront per window (posterior_tiled_wave.h) unless TP_TILED_WAVE=0
-        if (!(tw && *tw && atoi(tw) == 0)) hipLaunchKernelGGL(tiled_diag_wave_kernel, dim3(G), dim3(64), 0, stream, a, ws, j);
+        if (wave_diag && fused) hipLaunchKernelGGL(tiled_diag_wave_kernel<true>, dim3(G), dim3(64), 0, stream, a, ws, j);
+        else if (wave_diag) hipLaunchKernelGGL(tiled_diag_wave_kernel<false>, dim3(G), dim3(64), 0, stream, a, ws, j);
         else hipLaunchKernelGGL(tiled_diag_kernel, dim3(G), dim3(NTHREADS), 0, stream, a, ws, j);
         if (T > 0) {
             if (fused) hipLaunchKernelGGL(tile64_syrk_trsm_kernel, xcd_grid(T, G), dim3(NTHREADS), 0, stream, a, ws, j);

@@ -246,6 +246,15 @@ __device__ __forceinline__ double tw_rsqrt_cubic(double d) {
 constexpr int tw_ta(int a, int b) { return a * 4 - a * (a - 1) / 2 + (b - a); }       // A tile (a, b), a <= b: 0..9
 constexpr int tw_ty(int b, int a) { return 10 + b * (b + 1) / 2 + a; }                 // Y tile (b, a), a <= b: 10..19
 
+__device__ __forceinline__ void tw_settle2(d4& c0, d4& c1) { asm volatile("s_nop 15\n\ts_nop 7" : "+a"(c0), "+a"(c1)); }
+__device__ __forceinline__ void tw_mfma_agpr_neg(d4& c, double a, double b) {
+    asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0 neg:[1,0,0]" : "+a"(c) : "v"(a), "v"(b));
+}
+
+// UPDATE: the block first takes its left-looking update A_jj -= sum_{q<j} R_qj' R_qj here (rows 0 .. 64 j - 1 of the arena,
+// columns of super-tile j: four operand loads and ten MFMAs per 4-row k-step, the tiles on and above the diagonal only)
+// instead of in a launch of its own (tile64_kernel<MODE_SYRK_DIAG>: 201 us per block step at k = 500, 8 % of the run).
+template <bool UPDATE>
 __global__ void __launch_bounds__(64, 1) tiled_diag_wave_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws, const int j) {
     constexpr int MLD = 17;
     __shared__ __attribute__((aligned(16))) double lds[256 + 256 + 16 * MLD];          // diagonal tile | identity | M_a
@@ -284,6 +293,44 @@ __global__ void __launch_bounds__(64, 1) tiled_diag_wave_kernel(const tp_kargs_t
             acc[tw_ty(a, c)] = x;
         });
     });
+    if (UPDATE && j > 0) {
+        const double* col = M + 64 * j + fr;                         // column 16 a + fr of super-tile j, row r: col[r KP + 16 a]
+        const int nks = 16 * j;
+        auto load = [&](double (&v)[4], int ks) __attribute__((always_inline)) {
+            const double* p = col + (long long)(4 * ks + fq) * KP;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) v[a] = p[16 * a];
+        };
+        auto step = [&](double (&v)[4]) __attribute__((always_inline)) {
+            static_for_t<0, 4>([&](auto ac) __attribute__((always_inline)) {
+                constexpr int a = decltype(ac)::value;
+                static_for_t<a, 4>([&](auto bc) __attribute__((always_inline)) {
+                    constexpr int b = decltype(bc)::value;
+                    tw_mfma_agpr_neg(acc[tw_ta(a, b)], v[a], v[b]);
+                });
+            });
+        };
+        double va[4], vb[4], vc[4];
+        load(va, 0);
+        load(vb, 1);
+        static_for_t<0, 10>([&](auto tc) __attribute__((always_inline)) { tw_pin1(acc[decltype(tc)::value]); });
+        int ks = 0;
+#pragma nounroll
+        for (; ks + 3 <= nks; ks += 3) {                   // nks = 16 j >= 16: whole triples, then one or two k-steps
+            load(vc, ks + 2 < nks ? ks + 2 : nks - 1);
+            step(va);
+            load(va, ks + 3 < nks ? ks + 3 : nks - 1);
+            step(vb);
+            load(vb, ks + 4 < nks ? ks + 4 : nks - 1);
+            step(vc);
+        }
+        if (ks < nks) {
+            step(va);
+            if (ks + 1 < nks) step(vb);
+        }
+        tw_settle8(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
+        tw_settle2(acc[8], acc[9]);
+    }
     double badacc = 0.0;
     static_for_t<0, 4>([&](auto ac) __attribute__((always_inline)) {
         constexpr int a = decltype(ac)::value;

@@ -132,7 +132,7 @@ def main(path):
     text = open(path).read().split("\n")
     kernels, cur = {}, None
     for ln in text:
-        m = re.match(r"^(_Z\w*(?:posterior_wave_kernel|tiled_gram_wave_kernel)\w*):", ln)
+        m = re.match(r"^(_Z\w*(?:posterior_wave_kernel|tiled_gram_wave_kernel|tiled_diag_wave_kernel)\w*):", ln)
         if m:
             cur = kernels.setdefault(m.group(1), [])
             continue
@@ -144,14 +144,18 @@ def main(path):
     if not kernels:
         print("no kernel with inline-assembly MFMAs in", path)
         return 2
-    rc = 0
+    rc, total = 0, 0
     for name, lines in kernels.items():
         findings, n = check_kernel(name, lines)
+        total += n
         print(f"{name}: {n} inline-asm MFMAs, {len(findings)} hazard finding(s)")
         for f in findings[:10]:
-            print("   ", f[1], " touches pending AGPRs", f[2])
-        if findings or n == 0:
+            print("   ", f[1], " touches pending registers", f[2])
+        if findings:
             rc = 1
+    if total == 0:            # the listing holds none of the instructions this check is about: wrong file, or a broken parse
+        print("no inline-assembly MFMA found in", path)
+        rc = 1
     return rc
 
 
