@@ -353,7 +353,7 @@ static int flush_gather(tp_handle_t h);
 
 extern "C" {
 
-const char* tp_version(void) { return "tangency-posterior 0.3.0 (gfx950, fp64 MFMA: register-tile kernel k<=239, tiled pipeline k<=2047)"; }
+const char* tp_version(void) { return "tangency-posterior 0.4.0 (gfx950, fp64 MFMA: one wavefront per window k<=143, multi-wave register tiles k<=239, tiled pipeline k<=2047)"; }
 
 int tp_max_assets(void) { return tp_tiled_max_assets(); }
 
