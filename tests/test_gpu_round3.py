@@ -91,3 +91,29 @@ def test_wave_kernel_flags_a_singular_window(native, kernel_choice):
     kernel_choice("1")
     w, s, _ = _run(native, "jeffreys", k, N, inp)
     assert (s != 0).all()
+
+
+def test_large_k_path_flags_singular_windows_and_agrees_across_its_kernel_forms(native):
+    """Large-k path (k >= 240): rank-deficient windows are flagged by the one-wave diagonal-block kernel; and its one-wave
+    kernels (Gram super-tile, diagonal block, fused update + TRSM) give the 4-wave kernels' weights (TP_TILED_WAVE=0,
+    TP_TILED_FUSE=0) to rounding on well-posed windows."""
+    k, N = 300, 120
+    inp = synthetic.make_kernel_inputs(k, N, 5, seed=11)
+    _, s, _ = _run(native, "jeffreys", k, N, inp)                      # 119 rows, 300 assets: singular
+    assert (s != 0).all()
+    k, N = 260, 700
+    inp = synthetic.make_kernel_inputs(k, N, 6, seed=12, hf_days=4)
+    old = {v: os.environ.get(v) for v in ("TP_TILED_WAVE", "TP_TILED_FUSE")}
+    try:
+        os.environ.pop("TP_TILED_WAVE", None); os.environ.pop("TP_TILED_FUSE", None)
+        w_new, s_new, _ = _run(native, "conjugate", k, N, inp)
+        os.environ["TP_TILED_WAVE"] = "0"; os.environ["TP_TILED_FUSE"] = "0"
+        w_old, s_old, _ = _run(native, "conjugate", k, N, inp)
+    finally:
+        for v, x in old.items():
+            if x is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = x
+    assert (s_new == 0).all() and (s_old == 0).all()
+    np.testing.assert_allclose(w_new, w_old, rtol=0, atol=1e-11)
