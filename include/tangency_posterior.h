@@ -124,7 +124,22 @@ int tp_device_count(void);
 /* Contexts.  tp_create binds device `device_id`, creates a stream and timing events.
  * Replaces: nothing in the reference (it has no device); corresponds to process start-up. */
 int tp_create(int device_id, tp_handle_t* out);
+/* Destroys the handle AND every batch of it that is still alive (their tp_batch_t become invalid).  Lifetime rule
+ * for host languages with finalisers: whatever is still alive when the process exits is taken down by the library's
+ * own exit handler (registered by the first tp_create, so it runs before the HIP / RCCL runtimes unload: batches
+ * first, then the communicator, streams, events); tp_destroy / tp_batch_destroy calls that arrive after that -
+ * from finalisers that run during interpreter shutdown - return TP_OK without touching the device or the handle. */
 int tp_destroy(tp_handle_t h);
+/* Tuning switches of a handle (A/B measurements, tests).  The environment variables of the same meaning
+ * (TP_WAVE_KERNEL, TP_TILED_WAVE, TP_TILED_FUSE, TP_NO_SHARED_GRAM, TP_TILED_ARENA_GIB, TP_TILED_ARENA_MIB) are read
+ * ONCE, in tp_create; afterwards only this call changes them - no launch reads the environment.
+ *   "wave_kernel"      -1 automatic | 0 multi-wave register-tile kernel | 1 one-wave kernel | 2 two-wave kernel
+ *   "tiled_wave"       -1 automatic | 0 four-wave Gram / diagonal-block kernels of the large-k path
+ *   "tiled_fuse"       -1 automatic | 0 / 1 three-kernel / fused left-looking update of the large-k path
+ *   "no_shared_gram"   1 = as if every batch carried TP_FLAG_NO_SHARED_GRAM (takes effect at the next upload)
+ *   "tiled_arena_gib" / "tiled_arena_mib"  in-flight arena of the large-k path (0: default)
+ * Replaces nothing in the reference. */
+int tp_set_option(tp_handle_t h, const char* name, int value);
 const char* tp_last_error(tp_handle_t h); /* h may be NULL: last error of a failed tp_create */
 int tp_device_info(tp_handle_t h, char* name, int name_len, int* compute_units, int* clock_mhz,
                    int64_t* hbm_bytes);

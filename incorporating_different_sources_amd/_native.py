@@ -5,8 +5,11 @@ the shared library (so that a missing build fails loudly); creating a `Device` n
 """
 from __future__ import annotations
 
+import atexit
 import ctypes
 import os
+import sys
+import threading
 import weakref
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
 
@@ -33,7 +36,8 @@ UNIQUE_ID_BYTES = 128
 
 # every symbol include/tangency_posterior.h declares (checked by tests/test_cabi_symbols.py)
 EXPORTS = [
-    "tp_version", "tp_max_assets", "tp_device_count", "tp_create", "tp_destroy", "tp_last_error", "tp_device_info",
+    "tp_version", "tp_max_assets", "tp_device_count", "tp_create", "tp_destroy", "tp_set_option", "tp_last_error",
+    "tp_device_info",
     "tp_log_returns", "tp_batch_create", "tp_batch_upload", "tp_batch_upload_async", "tp_batch_upload_wait",
     "tp_batch_shared_gram_blocks",
     "tp_host_alloc", "tp_host_free", "tp_batch_set_rhs", "tp_batch_set_shift", "tp_batch_keep_rhs",
@@ -79,6 +83,7 @@ def _load():
     lib.tp_max_assets.restype = c_int
     lib.tp_create.argtypes = [c_int, POINTER(c_void_p)]
     lib.tp_destroy.argtypes = [c_void_p]
+    lib.tp_set_option.argtypes = [c_void_p, c_char_p, c_int]
     lib.tp_device_info.argtypes = [c_void_p, c_char_p, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int64)]
     lib.tp_log_returns.argtypes = [c_void_p, POINTER(c_double), c_int64, c_int32, POINTER(c_int32), POINTER(c_int32),
                                    c_int64, POINTER(c_double)]
@@ -150,6 +155,56 @@ def _arr(a, dtype, shape=None, name=""):
     return a
 
 
+# ---- lifetime --------------------------------------------------------------------------------------------------------
+# Device memory, streams, events and RCCL communicators must be released while the HIP / RCCL runtimes are still up.
+# Objects that outlive their scope - locals of a frame kept by a traceback after a failed backtest, module globals -
+# used to reach __del__ during interpreter finalisation or never, and the process then aborted in the runtimes' own
+# static teardown (round 2: `std::bad_variant_access`, core dumps after a failing test).  Rule: every live Device and
+# pinned block is tracked here and closed by ONE atexit hook (atexit hooks run before module teardown and before any
+# C-level exit handler: batches first, then the communicator, streams, the handle); finalisers that run once the
+# interpreter is finalising do nothing (the library's own exit handler covers whatever is left, see tp_destroy).
+_live_devices: "weakref.WeakSet" = weakref.WeakSet()
+_live_pinned: "weakref.WeakSet" = weakref.WeakSet()
+_live_lock = threading.Lock()
+_closed_for_exit = False
+
+
+def _finalizing() -> bool:
+    return _closed_for_exit or sys.is_finalizing()
+
+
+def shutdown() -> None:
+    """Close every live Device (its batches first) and free every pinned block.  Runs at interpreter exit; safe to
+    call earlier (objects created afterwards are tracked again)."""
+    with _live_lock:
+        devices = list(_live_devices)
+        pinned = list(_live_pinned)
+    for d in devices:
+        try:
+            d.close()
+        except Exception:
+            pass
+    for p in pinned:
+        try:
+            p.free()
+        except Exception:
+            pass
+    global _default_device, _default_group
+    _default_device = None
+    _default_group = None
+
+
+def _shutdown_at_exit() -> None:
+    global _closed_for_exit
+    try:
+        shutdown()
+    finally:
+        _closed_for_exit = True
+
+
+atexit.register(_shutdown_at_exit)
+
+
 class _PinnedBlock:
     """Owner of one tp_host_alloc block; numpy arrays made over it keep it alive through `.base`."""
 
@@ -160,12 +215,19 @@ class _PinnedBlock:
             raise TangencyError(rc, f"tp_host_alloc({nbytes}) failed")
         self.nbytes = int(nbytes)
         self.buf = (ctypes.c_char * max(1, self.nbytes)).from_address(self.ptr.value)
+        with _live_lock:
+            _live_pinned.add(self)
+
+    def free(self):
+        if self.ptr:
+            lib.tp_host_free(self.ptr)
+            self.ptr = c_void_p()
 
     def __del__(self):
+        if _finalizing():        # the runtime may be unloading: leak (the process is ending)
+            return
         try:
-            if self.ptr:
-                lib.tp_host_free(self.ptr)
-                self.ptr = c_void_p()
+            self.free()
         except Exception:
             pass
 
@@ -200,6 +262,15 @@ class Device:
         if rc != TP_OK:
             raise TangencyError(rc, lib.tp_last_error(None).decode())
         self.device_id = device_id
+        with _live_lock:
+            _live_devices.add(self)
+
+    def set_option(self, name: str, value: int):
+        """`tp_set_option`: kernel-selection switches of this handle ("wave_kernel", "tiled_wave", "tiled_fuse",
+        "no_shared_gram", "tiled_arena_gib", "tiled_arena_mib"); the TP_* environment variables are read once, when the
+        Device is created."""
+        self._check(lib.tp_set_option(self._h, name.encode(), int(value)))
+        return self
 
     def _check(self, rc):
         if rc != TP_OK:
@@ -207,12 +278,22 @@ class Device:
 
     def close(self):
         if self._h:
-            for b in list(self._batches):      # a batch must not outlive its handle (tp_batch_destroy dereferences it)
+            for b in list(self._batches):      # a batch must not outlive its handle (tp_destroy would take it down too)
                 b.close()
             lib.tp_destroy(self._h)
             self._h = c_void_p()
+        with _live_lock:
+            _live_devices.discard(self)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def __del__(self):
+        if _finalizing():        # see "lifetime" above: never call into HIP / RCCL from a finaliser at exit
+            return
         try:
             self.close()
         except Exception:
@@ -304,10 +385,19 @@ class Batch:
 
     def close(self):
         if self._b:
-            lib.tp_batch_destroy(self._b)
+            if self.dev._h:                    # a closed Device took its batches with it
+                lib.tp_batch_destroy(self._b)
             self._b = c_void_p()
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def __del__(self):
+        if _finalizing():
+            return
         try:
             self.close()
         except Exception:

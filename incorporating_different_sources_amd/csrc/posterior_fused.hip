@@ -11,9 +11,8 @@ TP_DECL(9) TP_DECL(10) TP_DECL(11) TP_DECL(12) TP_DECL(13) TP_DECL(14) TP_DECL(1
 
 int tp_fused_max_assets(void) { return 16 * TP_MAX_NT - 1; }
 
-bool tp_use_wave_kernel(int nt) {
-    const char* e = getenv("TP_WAVE_KERNEL");      // read per launch: a test process may flip it between runs
-    if (e && *e) return atoi(e) != 0;
+bool tp_use_wave_kernel(int nt, int choice) {
+    if (choice >= 0) return choice != 0;
     // measured on MI355X (tools/sweep_k.py, both kernels in one run, gpurun_out/r03f/sweep.log and the round's later runs):
     // one wave per window wins at every tile count it is built for: +10 % (k = 8) .. +55 % (k = 55), +24 % at k = 100,
     // +22..31 % at 8 tiles (k = 112..127: four of the 36 tiles live in VGPRs), +15 % .. -2 % at 9 tiles (k = 128..143).
@@ -37,6 +36,10 @@ hipError_t tp_fused_launch(const tp_kargs_t& a, int grid, hipStream_t stream, tp
 // TP_WINSUM_RUN consecutive positions - the first sum of the run is taken in full (ascending blocks), the following ones
 // slide (add the entering block, subtract the leaving one), so the rounding of Q_L[b0] depends on the panel and on b0
 // alone.  HBM / L2-bound: reads 2 slots and writes 1 per position.
+// Non-finite panel values (a NaN row; an infinite price ratio that the front-end clamps to +-DBL_MAX, whose square
+// overflows) must poison exactly the windows that CONTAIN them: a sliding difference would carry Inf - Inf = NaN into
+// every later position of the run.  So a position whose previous sum is not finite is summed in full again - while the
+// bad block is inside the window that is the same NaN / Inf, once it has left it is the clean sum.
 typedef double tp_d2 __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(256) tp_window_sums_kernel(const tp_d2* __restrict__ G, tp_d2* __restrict__ Q, int nblk,
                                                              long long slot_pairs, int4 Ls, int n_L) {
@@ -48,12 +51,19 @@ __global__ void __launch_bounds__(256) tp_window_sums_kernel(const tp_d2* __rest
     const int bs = blockIdx.y * TP_WINSUM_RUN;
     if (li >= n_L || L < 1 || bs >= npos) return;
     const int be = bs + TP_WINSUM_RUN < npos ? bs + TP_WINSUM_RUN : npos;
-    tp_d2 sum = G[(long long)bs * slot_pairs + e];
-    for (int b = bs + 1; b < bs + L; ++b) sum += G[(long long)b * slot_pairs + e];
+    auto full = [&](int b0) {
+        tp_d2 acc = G[(long long)b0 * slot_pairs + e];
+        for (int b = b0 + 1; b < b0 + L; ++b) acc += G[(long long)b * slot_pairs + e];
+        return acc;
+    };
+    tp_d2 sum = full(bs);
     tp_d2* out = Q + (long long)li * nblk * slot_pairs;
     out[(long long)bs * slot_pairs + e] = sum;
     for (int b0 = bs + 1; b0 < be; ++b0) {
-        sum += G[(long long)(b0 + L - 1) * slot_pairs + e] - G[(long long)(b0 - 1) * slot_pairs + e];
+        if (__builtin_isfinite(sum[0]) && __builtin_isfinite(sum[1]))
+            sum += G[(long long)(b0 + L - 1) * slot_pairs + e] - G[(long long)(b0 - 1) * slot_pairs + e];
+        else
+            sum = full(b0);
         out[(long long)b0 * slot_pairs + e] = sum;
     }
 }

@@ -1260,13 +1260,8 @@ inline bool tp_layout_is_lean(const tp_kargs_t& a) {
 template <int NT, int NW, bool LEAN>
 hipError_t launch_variant(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info) {
     using C = Cfg<NT, NW>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)posterior_fused_kernel<NT, NW, LEAN>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};      // one bit per device (tp_allow_dynamic_lds)
+    { hipError_t e = tp_allow_dynamic_lds(attr_done, posterior_fused_kernel<NT, NW, LEAN>, C::LDS_BYTES); if (e != hipSuccess) return e; }
     if (info) { info->grid = grid; info->block = C::NTHREADS; info->lds_bytes = C::LDS_BYTES; info->ntile = NT; }
     const int grid8 = 8 * ((grid + 7) / 8);            // whole rounds of the 8 XCDs (window_body maps ids to windows)
     hipLaunchKernelGGL((posterior_fused_kernel<NT, NW, LEAN>), dim3(grid8), dim3(C::NTHREADS), C::LDS_BYTES, stream, a);
@@ -1284,13 +1279,8 @@ hipError_t launch_one(const tp_kargs_t& a, int grid, hipStream_t stream, tp_laun
     if (!tp_layout_is_lean(a)) return wave ? wave(a, grid, stream, info, false) : launch_variant<NT, NW, false>(a, grid, stream, info);
     if (a.winsum != nullptr) {
         // the shared sums first, on the same stream: part of every run, nothing is kept between runs
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute((const void*)block_gram_kernel<NT, NW>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-            if (e != hipSuccess) return e;
-            attr_done = true;
-        }
+        static std::atomic<unsigned long long> attr_done{0};
+        { hipError_t e = tp_allow_dynamic_lds(attr_done, block_gram_kernel<NT, NW>, C::LDS_BYTES); if (e != hipSuccess) return e; }
         hipLaunchKernelGGL((block_gram_kernel<NT, NW>), dim3((unsigned)a.prefix_nblk), dim3(C::NTHREADS), C::LDS_BYTES, stream, a,
                            (double*)a.prefix);
         hipError_t e = hipGetLastError();

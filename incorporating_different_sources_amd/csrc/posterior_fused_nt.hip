@@ -24,6 +24,6 @@ hipError_t TP_CAT(tp_fused_launch_nt, TP_NT)(const tp_kargs_t& a, int grid, hipS
     constexpr int NW = tp_waves_for_tiles(TP_NT);
     if (want_occupancy) { *want_occupancy = blocks_per_cu<TP_NT, NW>(); return hipSuccess; }
     tp_wave_launch_fn wave = TP_WAVE_FN;
-    if (!tp_use_wave_kernel(TP_NT)) wave = nullptr;
+    if (!tp_use_wave_kernel(TP_NT, a.opts.wave_kernel)) wave = nullptr;
     return launch_one<TP_NT, NW>(a, grid, stream, info, wave);
 }

@@ -8,6 +8,32 @@
 #define TP_KSTATUS_NONFINITE 2
 #define TP_KSTATUS_BAD_DENOM 3
 
+// Kernel-selection switches of a handle (A/B measurements and tests).  -1 = automatic.  Read from the environment once,
+// in tp_create (TP_WAVE_KERNEL, TP_TILED_WAVE, TP_TILED_FUSE), changed through tp_set_option; the launchers read
+// them from the batch's arguments, never from the environment.
+struct tp_kopts_t {
+    int wave_kernel = -1;   // register-tile path: 0 = multi-wave kernel, 1 = one-wave kernel (k <= 143), 2 = two-wave kernel
+    int tiled_wave = -1;    // large-k path: 0 = the 4-wave Gram / diagonal-block kernels
+    int tiled_fuse = -1;    // large-k path: 0 / 1 = three-kernel / fused left-looking update + solve
+};
+
+// Dynamic-LDS limit of a kernel: a per-DEVICE function attribute.  The one-process-all-GPUs mode launches the same
+// kernel on several devices from several host threads, so "already set" is a bit per device ordinal (devices beyond
+// 63 set it on every launch).
+#include <atomic>
+template <typename K>
+inline hipError_t tp_allow_dynamic_lds(std::atomic<unsigned long long>& done_mask, K kernel, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
+    if (bit && (done_mask.load(std::memory_order_acquire) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    if (bit) done_mask.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}
+
 // Device-side view of one batch (all pointers are DEVICE pointers; optional ones may be null).
 struct tp_kargs_t {
     const double* panel;
@@ -46,6 +72,7 @@ struct tp_kargs_t {
     int phase_limit;      // diagnostic (TP_PHASE_LIMIT): 1 = stop after the Gram phases (outputs are then invalid)
     int center_rows;      // Jeffreys: 0 = J = T - t t'/N, 1 = divide by the window's row count instead, 2 = plain T
     double gamma;
+    tp_kopts_t opts;      // host-side only: which kernels run this batch
 };
 
 struct tp_launch_info_t { int grid, block, lds_bytes, ntile; };
@@ -68,8 +95,8 @@ hipError_t tp_window_sums_launch(const double* G, double* Q, int nblk, size_t sl
                                  hipStream_t stream);
 
 // which register-tile kernel runs a tile count: the one-wave-per-window kernel (posterior_wave_impl.h) or the
-// multi-wave kernel (posterior_fused_impl.h); TP_WAVE_KERNEL=0 / 1 in the environment overrides it (A/B measurements)
-bool tp_use_wave_kernel(int nt);
+// multi-wave kernel (posterior_fused_impl.h); `choice` = tp_kopts_t::wave_kernel overrides it (A/B measurements)
+bool tp_use_wave_kernel(int nt, int choice);
 // 0 / 1: a plain conjugate / Jeffreys batch (weights, statuses, aux only) - what the one-wave kernel is built for;
 // 2: a batch with a matrix read-back, a custom right-hand side, tp_batch_keep_rhs, a shift or a non-default centring
 inline int wave_mode(const tp_kargs_t& a) {

@@ -915,9 +915,8 @@ hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStre
         else hipLaunchKernelGGL(tiled_prior_kernel<32>, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
     }
     // one wavefront per super-tile (posterior_tiled_wave.h) unless TP_TILED_WAVE=0 asks for the 4-wave kernels (A/B runs)
-    const char* tw = getenv("TP_TILED_WAVE");
-    const char* tf = getenv("TP_TILED_FUSE");
-    if (!(tw && *tw && atoi(tw) == 0))
+    const bool use_wave = a.opts.tiled_wave != 0;
+    if (use_wave)
         hipLaunchKernelGGL(tiled_gram_wave_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(64), 0, stream, a, ws);
     else if (lean) hipLaunchKernelGGL(tiled_gram_lean_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws);
     else hipLaunchKernelGGL(tile64_kernel<MODE_GRAM>, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws, 0);
@@ -930,10 +929,10 @@ hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStre
         const int T = NS - 1 - j;
         // measured (TP_TILED_FUSE = 0 / 1 runs of round 2): fused +1.6..2 % at k = 500 (8 super-tiles per side), -1.5 % at
         // k = 1000 (16: the fused kernel's longer workgroups balance worse over the many tiles of a block row)
-        const bool fused = (tf && *tf) ? atoi(tf) != 0 : NS <= 8;
+        const bool fused = a.opts.tiled_fuse >= 0 ? a.opts.tiled_fuse != 0 : NS <= 8;
         // the left-looking update: of the diagonal tile only (the rest of the row takes it together with its solve below), or of
         // the whole row (TP_TILED_FUSE=0: the three-kernel form, for A/B runs)
-        const bool wave_diag = !(tw && *tw && atoi(tw) == 0);
+        const bool wave_diag = use_wave;
         // fused: the diagonal tile takes its update inside the one-wave diagonal-block kernel (or in a launch of its own in
         // front of the 4-wave one), the rest of the row together with its solve below
         if (j > 0 && fused && !wave_diag) hipLaunchKernelGGL(tile64_kernel<MODE_SYRK_DIAG>, xcd_grid(1, G), dim3(NTHREADS), 0, stream, a, ws, j);

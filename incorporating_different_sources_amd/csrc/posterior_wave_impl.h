@@ -769,13 +769,8 @@ __global__ void __launch_bounds__(64, wave_occupancy(NT)) posterior_wave_kernel(
 template <int NT, bool LEAN, int MODE>
 hipError_t wave_launch_mode(const tp_kargs_t& a, int grid8, hipStream_t stream) {
     using C = WCfg<NT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)posterior_wave_kernel<NT, LEAN, MODE>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};      // one bit per device (tp_allow_dynamic_lds)
+    { hipError_t e = tp_allow_dynamic_lds(attr_done, posterior_wave_kernel<NT, LEAN, MODE>, C::LDS_BYTES); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL((posterior_wave_kernel<NT, LEAN, MODE>), dim3(grid8), dim3(64), C::LDS_BYTES, stream, a);
     return hipGetLastError();
 }

@@ -8,7 +8,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
 #include <initializer_list>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -44,7 +47,16 @@ struct tp_handle_s {
     hipEvent_t cp0 = nullptr, cp1 = nullptr;
     bool copy_timed = false;
     bool gather_timed = false;
-    tp_batch_t deferred = nullptr;  // batch whose tp_batch_gather_async is requested but not yet on the gather stream      // cg0/cg1 bracket the last asynchronous gather and have not been read yet
+    tp_batch_t deferred = nullptr;  // batch whose tp_batch_gather_async is requested but not yet on the gather stream
+    // Tuning switches (A/B measurements, tests): read from the environment ONCE, in tp_create, and changed only through
+    // tp_set_option on this handle - no launch path reads the environment (several host threads launch at once in the
+    // one-process-all-GPUs mode while a test may be changing it).
+    tp_kopts_t opts{};
+    int no_shared_gram = 0;         // TP_NO_SHARED_GRAM / "no_shared_gram"
+    int tiled_arena_gib = 0;        // TP_TILED_ARENA_GIB / "tiled_arena_gib" (0: default)
+    int tiled_arena_mib = 0;        // TP_TILED_ARENA_MIB / "tiled_arena_mib": a sub-GiB arena (depth-first sub-batches)
+    int phase_limit = 0;            // TP_PHASE_LIMIT (diagnostic builds only)
+    std::vector<tp_batch_t> batches;   // live batches of this handle (destroyed with it if the caller forgot them)
 };
 
 struct DevBuf {
@@ -68,7 +80,7 @@ struct tp_batch_s {
     bool uploaded = false;
     bool gathered = false;
     bool rhs_valid = false;                          // out_rhs was allocated before the last run (tp_batch_keep_rhs)
-    hipEvent_t ran = nullptr;                        // end of this batch's last launch (recorded once asynchronous uploads are in use)
+    hipEvent_t ran = nullptr;                        // end of this batch's last launch (recorded by every tp_batch_run)
     hipEvent_t upload_done = nullptr;                // tp_batch_upload_async: end of the copies on the copy stream
     bool upload_pending = false;
     // tp_batch_gather_async: results alternate between (weights, status) and (weights2, status2), so that the
@@ -85,6 +97,38 @@ struct tp_batch_s {
 };
 
 namespace {
+
+// ---- lifetime ---------------------------------------------------------------------------------------------------
+// Every live handle is registered here.  A C atexit handler - registered by the first tp_create, i.e. AFTER the HIP and
+// RCCL libraries registered their own static teardown, so it runs BEFORE them - destroys what the caller left alive
+// (batches first, then the RCCL communicator, streams, events) while the runtimes still work, and then marks the
+// library as shut down: a tp_destroy / tp_batch_destroy that arrives later (an object finalised by a host language
+// during its own exit) frees nothing on the device and makes no HIP / RCCL call.  Round 2's exit-time aborts
+// (std::bad_variant_access, a core dump after a failed test) were exactly such calls and leaked communicators.
+std::mutex g_registry_mutex;
+std::vector<tp_handle_t> g_live_handles;
+std::atomic<bool> g_shut_down{false};
+bool g_atexit_registered = false;
+
+bool runtime_gone(hipError_t e) {
+    return e == hipErrorDeinitialized || e == hipErrorNotInitialized || e == hipErrorContextIsDestroyed ||
+           e == hipErrorInvalidContext;
+}
+
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
+int destroy_handle(tp_handle_t h, bool device_calls);
+int destroy_batch(tp_batch_t b, bool device_calls);
+
+void shutdown_at_exit() {
+    std::vector<tp_handle_t> live;
+    { std::lock_guard<std::mutex> lk(g_registry_mutex); live.swap(g_live_handles); }
+    for (tp_handle_t h : live) (void)destroy_handle(h, true);
+    g_shut_down.store(true);
+}
 
 int fail(tp_handle_t h, int code, const char* fmt, ...) {
     char buf[512];
@@ -179,8 +223,9 @@ tp_kargs_t make_kargs(tp_batch_t b) {
     a.center_rows = (b->p.flags & TP_FLAG_NO_CENTER) ? 2 : (b->p.flags & TP_FLAG_CENTER_BY_ROWS) ? 1 : 0;
     a.phase_limit = 0;
 #ifdef TP_STAMP
-    { const char* pl = getenv("TP_PHASE_LIMIT"); a.phase_limit = pl ? atoi(pl) : 0; }   // diagnostic build only
+    a.phase_limit = b->h->phase_limit;                // diagnostic build only (TP_PHASE_LIMIT, read in tp_create)
 #endif
+    a.opts = b->h->opts;
     a.weights = b->out_weights();
     a.status = (int*)b->out_status();
     a.aux = (double*)b->aux.p;
@@ -296,8 +341,10 @@ int ensure_tiled_ws(tp_batch_t b, tp_tiled_ws_t* ws) {
     unsigned long long gib = 32;
     { size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (free_b >> 30) / 3 < gib) gib = (free_b >> 30) / 3 > 1 ? (free_b >> 30) / 3 : 1; }
-    if (const char* e = getenv("TP_TILED_ARENA_GIB")) { const long v = atol(e); if (v >= 1 && v <= 200) gib = (unsigned long long)v; }
-    int64_t G = (int64_t)((gib << 30) / per_window);
+    if (h->tiled_arena_gib >= 1 && h->tiled_arena_gib <= 200) gib = (unsigned long long)h->tiled_arena_gib;
+    unsigned long long arena_bytes = gib << 30;
+    if (h->tiled_arena_mib >= 1 && h->tiled_arena_mib <= 200 * 1024) arena_bytes = (unsigned long long)h->tiled_arena_mib << 20;
+    int64_t G = (int64_t)(arena_bytes / per_window);
     if (G < 1) G = 1;
     if (G > b->W) G = b->W;
     if (G > 65535) G = 65535;
@@ -351,9 +398,62 @@ int launch(tp_batch_t b, const tp_kargs_t& a, int64_t count, bool timed) {
 static int harvest_kernel_time(tp_handle_t h);
 static int flush_gather(tp_handle_t h);
 
+namespace {
+
+// device_calls = false, or a runtime that answers "deinitialised": only the host structures go.
+int destroy_batch(tp_batch_t b, bool device_calls) {
+    tp_handle_t h = b->h;
+    if (device_calls && runtime_gone(hipSetDevice(h->device))) device_calls = false;
+    if (device_calls) {
+        // A gather that was requested (tp_batch_gather_async) but not yet put on its stream is a collective the peer
+        // ranks may already be waiting in: issue it before the buffers go away - dropping it would hang them.
+        if (h->deferred == b) (void)flush_gather(h);
+        (void)hipStreamSynchronize(h->stream);
+        if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);   // a gather may still read the results
+        for (hipEvent_t e : b->gather_done)
+            if (e) (void)hipEventDestroy(e);
+        if (b->snap) (void)hipEventDestroy(b->snap);
+        if (b->upload_done) { (void)hipEventSynchronize(b->upload_done); (void)hipEventDestroy(b->upload_done); }
+        if (b->ran) (void)hipEventDestroy(b->ran);
+        DevBuf* all[] = {&b->fe_prices, &b->fe_num, &b->fe_den, &b->fe_hf_prices, &b->fe_hf_num, &b->fe_hf_den,
+                         &b->panel, &b->start, &b->row_idx, &b->n_rows, &b->col_idx, &b->rf_adj, &b->hf_panel, &b->hf_start,
+                         &b->hf_row_idx, &b->hf_count, &b->w0, &b->n0, &b->weights, &b->status, &b->aux, &b->dbg,
+                         &b->gather_w, &b->gather_s, &b->weights2, &b->status2, &b->stamps, &b->rhs, &b->out_rhs, &b->shift,
+                         &b->prefix, &b->t_arena, &b->t_rinv, &b->t_ybar, &b->t_zc, &b->t_scal, &b->t_flags};
+        for (DevBuf* d : all) release(*d);
+    }
+    if (h->deferred == b) h->deferred = nullptr;
+    delete b;
+    return TP_OK;
+}
+
+int destroy_handle(tp_handle_t h, bool device_calls) {
+    if (device_calls && runtime_gone(hipSetDevice(h->device))) device_calls = false;
+    // batches the caller left alive go first: they hold device memory, events and possibly a requested gather
+    std::vector<tp_batch_t> left;
+    left.swap(h->batches);
+    for (tp_batch_t b : left) (void)destroy_batch(b, device_calls);
+    if (device_calls) {
+        if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
+        for (hipEvent_t e : {h->cg0, h->cg1})
+            if (e) (void)hipEventDestroy(e);
+        if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+        if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+        for (hipEvent_t e : {h->cp0, h->cp1, h->ev0, h->ev1, h->reg0, h->reg1})
+            if (e) (void)hipEventDestroy(e);
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+    }
+    delete h;
+    return TP_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
-const char* tp_version(void) { return "tangency-posterior 0.4.0 (gfx950, fp64 MFMA: one wavefront per window k<=143, multi-wave register tiles k<=239, tiled pipeline k<=2047)"; }
+const char* tp_version(void) { return "tangency-posterior 0.5.0 (gfx950, fp64 MFMA: one wavefront per window k<=143, multi-wave register tiles k<=239, tiled pipeline k<=2047)"; }
 
 int tp_max_assets(void) { return tp_tiled_max_assets(); }
 
@@ -393,29 +493,46 @@ int tp_create(int device_id, tp_handle_t* out) {
     CREATE_TRY(hipEventCreate(&h->reg0));
     CREATE_TRY(hipEventCreate(&h->reg1));
 #undef CREATE_TRY
+    // the environment is read here and nowhere else (see tp_handle_s::opts)
+    h->opts.wave_kernel = env_int("TP_WAVE_KERNEL", -1);
+    h->opts.tiled_wave = env_int("TP_TILED_WAVE", -1);
+    h->opts.tiled_fuse = env_int("TP_TILED_FUSE", -1);
+    h->no_shared_gram = getenv("TP_NO_SHARED_GRAM") != nullptr ? 1 : 0;
+    h->tiled_arena_gib = env_int("TP_TILED_ARENA_GIB", 0);
+    h->tiled_arena_mib = env_int("TP_TILED_ARENA_MIB", 0);
+    h->phase_limit = env_int("TP_PHASE_LIMIT", 0);
+    {
+        std::lock_guard<std::mutex> lk(g_registry_mutex);
+        if (!g_atexit_registered) { atexit(shutdown_at_exit); g_atexit_registered = true; }
+        g_live_handles.push_back(h);
+    }
     *out = h;
+    return TP_OK;
+}
+
+int tp_set_option(tp_handle_t h, const char* name, int value) {
+    if (!h || !name) return TP_ERR_INVALID;
+    const std::string n(name);
+    if (n == "wave_kernel") h->opts.wave_kernel = value;
+    else if (n == "tiled_wave") h->opts.tiled_wave = value;
+    else if (n == "tiled_fuse") h->opts.tiled_fuse = value;
+    else if (n == "no_shared_gram") h->no_shared_gram = value != 0;
+    else if (n == "tiled_arena_gib") h->tiled_arena_gib = value;
+    else if (n == "tiled_arena_mib") h->tiled_arena_mib = value;
+    else return fail(h, TP_ERR_INVALID, "tp_set_option: unknown option '%s'", name);
     return TP_OK;
 }
 
 int tp_destroy(tp_handle_t h) {
     if (!h) return TP_OK;
-    (void)hipSetDevice(h->device);
-    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
-    if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (hipEvent_t e : {h->cg0, h->cg1})
-        if (e) (void)hipEventDestroy(e);
-    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
-    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
-    for (hipEvent_t e : {h->cp0, h->cp1})
-        if (e) (void)hipEventDestroy(e);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->reg0) (void)hipEventDestroy(h->reg0);
-    if (h->reg1) (void)hipEventDestroy(h->reg1);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
-    delete h;
-    return TP_OK;
+    if (g_shut_down.load()) return TP_OK;           // the exit handler already took every live handle down (h is gone)
+    {
+        std::lock_guard<std::mutex> lk(g_registry_mutex);
+        auto it = std::find(g_live_handles.begin(), g_live_handles.end(), h);
+        if (it == g_live_handles.end()) return TP_OK;   // not (or no longer) a live handle: never touch it
+        g_live_handles.erase(it);
+    }
+    return destroy_handle(h, true);
 }
 
 int tp_device_info(tp_handle_t h, char* name, int name_len, int* compute_units, int* clock_mhz, int64_t* hbm_bytes) {
@@ -468,33 +585,19 @@ int tp_batch_create(tp_handle_t h, const tp_params_t* p, int64_t W, tp_batch_t* 
     rc = ensure(h, b->weights, sizeof(double) * (size_t)W * p->k);
     if (rc == TP_OK) rc = ensure(h, b->status, sizeof(int32_t) * (size_t)W);
     if (rc == TP_OK) rc = ensure(h, b->aux, sizeof(double) * (size_t)W * TP_AUX_STRIDE);
-    if (rc != TP_OK) { tp_batch_destroy(b); return rc; }
+    if (rc != TP_OK) { destroy_batch(b, true); return rc; }
+    h->batches.push_back(b);
     *out = b;
     return TP_OK;
 }
 
 int tp_batch_destroy(tp_batch_t b) {
     if (!b) return TP_OK;
-    (void)hipSetDevice(b->h->device);
-    // A gather that was requested (tp_batch_gather_async) but not yet put on its stream is a collective the peer
-    // ranks may already be waiting in: issue it before the buffers go away - dropping it would hang them.
-    if (b->h->deferred == b) (void)flush_gather(b->h);
-    (void)hipStreamSynchronize(b->h->stream);
-    if (b->h->comm_stream) (void)hipStreamSynchronize(b->h->comm_stream);   // a gather may still read the results
-    if (b->h->deferred == b) b->h->deferred = nullptr;
-    for (hipEvent_t e : b->gather_done)
-        if (e) (void)hipEventDestroy(e);
-    if (b->snap) (void)hipEventDestroy(b->snap);
-    if (b->upload_done) { (void)hipEventSynchronize(b->upload_done); (void)hipEventDestroy(b->upload_done); }
-    if (b->ran) (void)hipEventDestroy(b->ran);
-    for (DevBuf* d : {&b->fe_prices, &b->fe_num, &b->fe_den, &b->fe_hf_prices, &b->fe_hf_num, &b->fe_hf_den}) release(*d);
-    DevBuf* all[] = {&b->panel, &b->start, &b->row_idx, &b->n_rows, &b->col_idx, &b->rf_adj, &b->hf_panel, &b->hf_start,
-                     &b->hf_row_idx, &b->hf_count, &b->w0, &b->n0, &b->weights, &b->status, &b->aux, &b->dbg,
-                     &b->gather_w, &b->gather_s, &b->weights2, &b->status2, &b->stamps, &b->rhs, &b->out_rhs, &b->shift, &b->prefix, &b->t_arena, &b->t_rinv, &b->t_ybar, &b->t_zc,
-                     &b->t_scal, &b->t_flags};
-    for (DevBuf* d : all) release(*d);
-    delete b;
-    return TP_OK;
+    if (g_shut_down.load()) return TP_OK;           // destroyed with its handle by the exit handler
+    tp_handle_t h = b->h;
+    auto it = std::find(h->batches.begin(), h->batches.end(), b);
+    if (it != h->batches.end()) h->batches.erase(it);
+    return destroy_batch(b, true);
 }
 
 // Rolling windows over one shared panel overlap almost entirely; the register-tile path then takes the whole aligned
@@ -507,7 +610,7 @@ static int plan_shared_gram(tp_batch_t b, const tp_inputs_t* in) {
     tp_handle_t h = b->h;
     b->prefix_nblk = 0;
     const tp_params_t& p = b->p;
-    if ((p.flags & TP_FLAG_NO_SHARED_GRAM) || getenv("TP_NO_SHARED_GRAM")) return TP_OK;
+    if ((p.flags & TP_FLAG_NO_SHARED_GRAM) || h->no_shared_gram) return TP_OK;
     if (in->row_idx || in->col_idx || in->rf_adj || !in->start) return TP_OK;
     const long long rows = in->ret_num ? in->ret_rows : in->panel_rows;
     int nblk = 0;
@@ -556,6 +659,8 @@ static int upload_common(tp_batch_t b, const tp_inputs_t* in, hipStream_t st, bo
     // a launch of THIS batch that is still running reads the buffers about to be overwritten: the copy stream waits
     // for it (other batches' launches on the kernel stream are what the copies are meant to run under)
     if (!wait && b->ran) HIP_TRY(h, hipStreamWaitEvent(st, b->ran, 0));
+    // a synchronous upload while an asynchronous one is still copying into the same buffers: let that one finish first
+    if (wait && b->upload_pending && b->upload_done) HIP_TRY(h, hipEventSynchronize(b->upload_done));
     hipEvent_t e0 = wait ? h->ev0 : h->cp0, e1 = wait ? h->ev1 : h->cp1;
     if (!wait && h->copy_timed) {     // read the previous asynchronous upload's span before its events are reused
         HIP_TRY(h, hipEventSynchronize(h->cp1));
@@ -748,10 +853,10 @@ int tp_batch_run(tp_batch_t b) {
     tp_kargs_t a = make_kargs(b);
     int rc = launch(b, a, b->W, true);
     if (rc != TP_OK) return rc;
-    if (b->upload_done) {             // asynchronous uploads in use: the next one must not overtake this launch
-        if (!b->ran) HIP_TRY(h, hipEventCreateWithFlags(&b->ran, hipEventDisableTiming));
-        HIP_TRY(h, hipEventRecord(b->ran, h->stream));
-    }
+    // the end of this launch, recorded on EVERY run: a later tp_batch_upload_async of this batch - also the first one,
+    // after synchronous uploads - makes the copy stream wait for it before it overwrites what the launch reads
+    if (!b->ran) HIP_TRY(h, hipEventCreateWithFlags(&b->ran, hipEventDisableTiming));
+    HIP_TRY(h, hipEventRecord(b->ran, h->stream));
     return flush_gather(h);      // with the next kernel queued, put the requested gather of the previous run on its stream
 }
 

@@ -18,7 +18,8 @@ the comparison portfolio), not part of the accelerated path.  Jorion's Bayes-Ste
 reuses the device's scatter + Cholesky solve with two right-hand sides, and so does the Greyserman
 hierarchical prior (ref:897-938), one ridge-shifted window per hyper-parameter draw.  Shrinkage and
 Black-Litterman (ref:703-817: pypfopt, not in the tree) are outside the scope of this build and raise
-NotImplementedError.
+NotImplementedError - unless the caller registers the reference's own two functions with
+`register_strategy` (a caller who has pypfopt), which the dispatch then calls date by date.
 """
 from __future__ import annotations
 
@@ -476,17 +477,70 @@ def calculate_jeffreys_portfolio(portfolio_spec, trading_date_ts, k_stock_prices
         win.close()
 
 
+# Strategies of the reference's dispatch (ref:999-1011) that this build does not compute (pypfopt 1.5.5 is an un-vendored
+# dependency: parity unpinned) can be supplied by the caller: name -> function with the REFERENCE's signature,
+#   shrinkage        f(portfolio_spec, trading_date_ts, k_stock_prices_df, risk_free_rate_df)              ref:703-706
+#   black_litterman  f(portfolio_spec, trading_date_ts, k_stock_market_caps_df, k_stock_prices_df,
+#                      risk_free_rate_df)                                                                  ref:759-763
+# returning the reference's frame (index 'Stock', column 'Weight').
+_EXTERNAL_STRATEGIES = {}
+
+
+def register_strategy(name, fn):
+    """Let the unchanged spec loop of src/main.py:48 finish: `register_strategy("shrinkage",
+    reference_module.calculate_shrinkage_portfolio)` (likewise "black_litterman") makes `calculate_portfolio_weights`
+    / `backtest_portfolio` call `fn` per rebalancing date with the frames the reference's dispatch passes
+    (ref:999-1011).  `fn=None` removes the registration (the strategy raises NotImplementedError again)."""
+    if name not in _OUT_OF_SCOPE:
+        raise ValueError(f"register_strategy: only {_OUT_OF_SCOPE} can be supplied from outside, not {name!r}")
+    if fn is None:
+        _EXTERNAL_STRATEGIES.pop(name, None)
+    elif not callable(fn):
+        raise TypeError("register_strategy: fn must be callable")
+    else:
+        _EXTERNAL_STRATEGIES[name] = fn
+
+
 def _not_in_scope(name):
+    strategy = name[len("calculate_"):-len("_portfolio")]
+
     def f(*args, **kwargs):
+        fn = _EXTERNAL_STRATEGIES.get(strategy)
+        if fn is not None:
+            return fn(*args, **kwargs)
         raise NotImplementedError(
             f"{name} is outside the scope of this build (SURVEY.md section 2: C9-C12); only the conjugate and "
-            "Jeffreys posteriors and the passive weightings are provided.")
+            "Jeffreys posteriors and the passive weightings are provided.  A caller who has pypfopt can supply the "
+            f"reference's function: portfolio_calculations.register_strategy({strategy!r}, fn).")
     f.__name__ = name
     return f
 
 
 calculate_shrinkage_portfolio = _not_in_scope("calculate_shrinkage_portfolio")
 calculate_black_litterman_portfolio = _not_in_scope("calculate_black_litterman_portfolio")
+
+
+def _external_weights_for_dates(trading_dates, portfolio_spec, market_data):
+    """A registered out-of-scope strategy, date by date, with the frames the reference's dispatch slices (ref:953-988,
+    999-1011); returns what `_weights_for_dates` returns."""
+    strategy = portfolio_spec["weighting_strategy"]
+    fn = _EXTERNAL_STRATEGIES[strategy]
+    members_of = _members_provider(market_data)
+    cols, labels, caps = batch.pack_universes(list(trading_dates), portfolio_spec, market_data, members_of=members_of)
+    rf = market_data["risk_free_rate_df"]
+    weights = np.full(caps.shape, np.nan)
+    for i, ts in enumerate(trading_dates):
+        uni = _Universe(ts, portfolio_spec, market_data)
+        if strategy == "shrinkage":
+            frame = fn(portfolio_spec, ts, uni.prices, rf)
+        else:
+            frame = fn(portfolio_spec, ts, uni.caps, uni.prices, rf)
+        col = frame["Weight"] if "Weight" in getattr(frame, "columns", ()) else frame.iloc[:, 0]
+        w = col.reindex(labels[i])
+        if w.isna().any():
+            raise ValueError(f"{strategy}: the registered function returned no weight for {list(w.index[w.isna()])} at {ts}")
+        weights[i] = w.to_numpy(dtype=np.float64)
+    return weights, labels, cols, caps
 
 
 def _jorion_from_solves(x_t, x_one, t, T, N, gamma):
@@ -730,17 +784,37 @@ def _pack_window(trading_date_ts, portfolio_spec, market_data):
     return item
 
 
-# windows below which one GPU is used even when several are visible (a launch per device has a fixed cost)
+# windows below which one GPU is used even when sharding is on (a launch per device has a fixed cost)
 SHARD_MIN_WINDOWS = int(os.environ.get("TP_SHARD_MIN_WINDOWS", "2048"))
+# The one-process-all-GPUs route is OPT-IN: `TP_SHARD=1` in the environment at import, or `use_device_group(group)`.
+# It has never run on more than one physical GPU (this build's boxes have one; the driver's multi-GPU bench uses one
+# PROCESS per GPU, bench.py), so a backtest on a multi-GPU node stays on one device unless asked - ADVICE r2.
+_shard_group = None
+_shard_opt_in = os.environ.get("TP_SHARD", "") not in ("", "0")
+
+
+def use_device_group(group=True):
+    """Shard the batched solves of `backtest_portfolio` over the devices of `group` (a `_native.DeviceGroup`; True:
+    every visible GPU, `_native.default_group()`; None / False: back to one device)."""
+    global _shard_group, _shard_opt_in
+    if group is None or group is False:
+        _shard_group, _shard_opt_in = None, False
+    elif group is True:
+        _shard_group, _shard_opt_in = None, True
+    else:
+        _shard_group, _shard_opt_in = group, True
 
 
 def _device_posterior_batch(strategy, k, N, gamma, kw):
-    """The batched device call behind every estimator: on a node with several visible GPUs and enough windows, the
-    windows shard over ALL of them inside this one process (`shard.run_sharded`: contiguous shards, one grouped RCCL
-    gather to device 0; the reference's driver is a single process, src/main.py:26); otherwise one device."""
+    """The batched device call behind every estimator: one device by default; with sharding opted in (`TP_SHARD=1` /
+    `use_device_group`), several visible GPUs and enough windows, the windows shard over the group inside this one
+    process (`shard.run_sharded`: contiguous shards, one grouped RCCL gather to device 0; the reference's driver is a
+    single process, src/main.py:26)."""
     n_windows = len(kw["n_rows"]) if kw.get("n_rows") is not None else len(kw["start"])
-    if n_windows >= SHARD_MIN_WINDOWS and _native.device_count() > 1:
-        return shard.run_sharded(_native.default_group(), strategy, k, N, gamma, kw, want_aux=True)
+    if _shard_opt_in and n_windows >= SHARD_MIN_WINDOWS:
+        group = _shard_group if _shard_group is not None else (_native.default_group() if _native.device_count() > 1 else None)
+        if group is not None and group.world > 1:
+            return shard.run_sharded(group, strategy, k, N, gamma, kw, want_aux=True)
     return _native.posterior_batch(strategy, k, N, gamma, **kw)
 
 
@@ -759,7 +833,11 @@ def _cache_slot(portfolio_spec, trading_dates, market_data):
     and is kept alive by the entry (its `id` cannot be recycled while the entry exists)."""
     frame = market_data["vix_prices_df" if "_vix_" in portfolio_spec["weighting_strategy"] else "epu_prices_df"]
     cache = batch.panels_for(market_data, portfolio_spec["rolling_window_frequency"]).weights_cache
-    return cache, (_spec_cache_key(portfolio_spec), _dates_key(trading_dates), id(frame)), frame
+    # the universe also depends on who answers "members of the index at this date": the caller's provider is part of
+    # the key and is kept alive by the entry, like the frame
+    provider = market_data.get("index_constituents") if isinstance(market_data, dict) else None
+    provider = provider if callable(provider) else None
+    return cache, (_spec_cache_key(portfolio_spec), _dates_key(trading_dates), id(frame), id(provider)), (frame, provider)
 
 
 def _weights_for_dates(trading_dates, portfolio_spec, market_data):
@@ -767,6 +845,8 @@ def _weights_for_dates(trading_dates, portfolio_spec, market_data):
     host pass (`batch.pack_windows`) and, for the estimators, one device batch."""
     strategy = portfolio_spec["weighting_strategy"]
     if strategy in _OUT_OF_SCOPE:
+        if strategy in _EXTERNAL_STRATEGIES:
+            return _external_weights_for_dates(trading_dates, portfolio_spec, market_data)
         _not_in_scope(f"calculate_{strategy}_portfolio")()
     if strategy not in _CONJUGATE and strategy not in ("jeffreys", "jorion", "greyserman", "vw", "ew"):
         logger.error("Unknown weights spec.")
@@ -782,9 +862,9 @@ def _weights_for_dates(trading_dates, portfolio_spec, market_data):
             weights = np.full(caps.shape, 1 / k)                         # ref:670-672
         return weights, labels, cols, caps
     if strategy in _CONJUGATE:
-        cache, key, frame = _cache_slot(portfolio_spec, trading_dates, market_data)
+        cache, key, owners = _cache_slot(portfolio_spec, trading_dates, market_data)
         hit = cache.get(key)
-        if hit is not None and hit[1] is frame:                          # filled by a cross-spec batch
+        if hit is not None and hit[1][0] is owners[0] and hit[1][1] is owners[1]:      # filled by a cross-spec batch
             return hit[0]
     kw, labels, caps = batch.pack_windows(list(trading_dates), portfolio_spec, market_data, members_of=members_of,
                                           return_caps=True)
@@ -842,29 +922,47 @@ def calculate_weights_for_specs(trading_dates, portfolio_specs_list, market_data
         if not same_gamma:
             w = 1.0 / sp["risk_aversion"] * w
         res = (w, labels, kw["col_idx"], caps)
-        cache, key, frame = _cache_slot(sp, trading_dates, market_data)
+        cache, key, owners = _cache_slot(sp, trading_dates, market_data)
         if len(cache) > 64:
             cache.clear()
-        cache[key] = (res, frame)
+        cache[key] = (res, owners)
         out.append(res)
     return out
 
 
+# Cross-spec prefetch of `backtest_portfolio` (off with TP_PREFETCH_SIBLINGS=0): at most this many windows per batch,
+# siblings beyond it wait for their own call
+PREFETCH_SIBLINGS = os.environ.get("TP_PREFETCH_SIBLINGS", "1") not in ("0", "")
+PREFETCH_MAX_WINDOWS = int(os.environ.get("TP_PREFETCH_MAX_WINDOWS", "65536"))
+
+
 def _prefetch_siblings(portfolio_spec, rebalance_dates, market_data):
     """`backtest_portfolio` is called once per spec (src/main.py:48): when the spec is a conjugate spec of the grid
-    `portfolio_specs.create_portfolio_specs()` returned last, solve all its conjugate siblings with the same
-    windows in the same device batch, so that their own `backtest_portfolio` calls find the weights ready."""
-    if portfolio_spec["weighting_strategy"] not in _CONJUGATE:
+    `portfolio_specs.create_portfolio_specs()` returned last, solve its conjugate siblings with the same windows in
+    the same device batch, so that their own `backtest_portfolio` calls find the weights ready.
+
+    Only an optimisation, so it never changes what the call itself does: the batch is capped
+    (`PREFETCH_MAX_WINDOWS` windows: the index arrays are replicated per spec), and ANY failure of the joint batch - a
+    sibling whose market data is missing or whose prior strength raises - is logged and dropped: the spec then runs on
+    its own, and the sibling's problem surfaces in the sibling's own `backtest_portfolio`, where the reference's loop
+    would raise it."""
+    if not PREFETCH_SIBLINGS or portfolio_spec["weighting_strategy"] not in _CONJUGATE:
         return
-    cache, key, frame = _cache_slot(portfolio_spec, rebalance_dates, market_data)
-    if key in cache and cache[key][1] is frame:
+    cache, key, owners = _cache_slot(portfolio_spec, rebalance_dates, market_data)
+    if key in cache and cache[key][1][0] is owners[0] and cache[key][1][1] is owners[1]:
         return
     family = _batch_family(portfolio_spec)
     siblings = [sp for sp in portfolio_specs.last_grid().values()
                 if sp["weighting_strategy"] in _CONJUGATE and _batch_family(sp) == family
-                and _spec_cache_key(sp) != _spec_cache_key(portfolio_spec)]
-    if siblings:
+                and _spec_cache_key(sp) != _spec_cache_key(portfolio_spec) and sp.get("risk_aversion")]
+    room = PREFETCH_MAX_WINDOWS // max(len(rebalance_dates), 1) - 1
+    siblings = siblings[:max(room, 0)]
+    if not siblings:
+        return
+    try:
         calculate_weights_for_specs(rebalance_dates, [portfolio_spec] + siblings, market_data)
+    except Exception as exc:      # noqa: BLE001 - see the docstring: the single-spec path decides what the caller sees
+        logger.warning(f"cross-spec prefetch dropped ({type(exc).__name__}: {exc}); solving {portfolio_spec.get('display_name')} alone")
 
 
 def calculate_portfolio_weights_batch(trading_dates, portfolio_spec, market_data):
@@ -1118,7 +1216,7 @@ def backtest_portfolios(portfolio_specs_dict, ts_start_date, ts_end_date, market
     """`backtest_portfolio` for a whole spec grid ({name: spec}, as `create_portfolio_specs` returns it): the
     conjugate specs that share their windows go to the device in ONE batch (`calculate_weights_for_specs`), then
     every spec is replayed.  Specs outside the scope of this build (shrinkage, Black-Litterman: pypfopt) are
-    skipped with a warning - the reference's own loop (src/main.py:48) would stop at the first of them."""
+    skipped with a warning unless the caller supplied them (`register_strategy`)."""
     trading_dates = [pd.Timestamp(ts) for ts in market_data["stock_prices_df"].index]
     trading_dates = [ts for ts in trading_dates if ts_start_date <= ts <= ts_end_date]
     groups = {}
@@ -1130,7 +1228,7 @@ def backtest_portfolios(portfolio_specs_dict, ts_start_date, ts_end_date, market
             calculate_weights_for_specs(rebalancing_schedule(trading_dates, specs[0]["rebalancing_frequency"]), specs, market_data)
     out = {}
     for name, sp in portfolio_specs_dict.items():
-        if sp["weighting_strategy"] in _OUT_OF_SCOPE:
+        if sp["weighting_strategy"] in _OUT_OF_SCOPE and sp["weighting_strategy"] not in _EXTERNAL_STRATEGIES:
             logger.warning(f"{name}: {sp['weighting_strategy']} is outside the scope of this build (pypfopt); skipped.")
             continue
         out[name] = backtest_portfolio(sp, ts_start_date, ts_end_date, market_data)

@@ -163,11 +163,40 @@ def gen_backtest(pc, holder, name, strategies, size, N, window_freq, rebal, n_da
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def gen_result_csv(pc, holder, name, strategies, size, N, window_freq, rebal, n_days, n_tickers, seed, start_idx):
+    """The on-disk result formats: the TEXT of the three files src/main.py:79-81 writes for a
+    backtest - `Series.to_csv(header=True)` twice and `DataFrame.to_csv(header=True)` - produced by the unmodified
+    reference's results.  Stored as data (strategy -> three strings) in tests/golden/<name>_csv.json."""
+    import json
+    md, tickers = synthetic.make_market_data(n_tickers=n_tickers, n_days=n_days, seed=seed)
+    holder["tickers"] = tickers
+    days = md["stock_prices_df"].index
+    out = dict(size=size, N=N, n_days=n_days, n_tickers=n_tickers, seed=seed, start_idx=start_idx,
+               window_freq=window_freq, rebal=rebal, pandas=pd.__version__, files={})
+    for strat in strategies:
+        simple = strat in ("vw", "ew")
+        spec = {"weighting_strategy": strat, "size": size, "risk_aversion": None if simple else 5,
+                "turnover_cost": 15, "rebalancing_frequency": rebal, "rolling_window": N,
+                "rolling_window_frequency": window_freq, "mcm_scaling": None if simple or strat == "jeffreys" else 1,
+                "display_name": "Display " + strat}
+        res = pc.backtest_portfolio(spec, days[start_idx], days[-1], md)
+        out["files"][strat] = {
+            "simple_returns": res["portfolio_simple_returns_series"].to_csv(header=True),          # src/main.py:79
+            "turnover": res["portfolio_turnover_series"].to_csv(header=True),                      # src/main.py:80
+            "portfolio_weights_metrics": res["portfolio_weights_metrics_df"].to_csv(header=True),  # src/main.py:81
+        }
+        print(f"  {name}_csv:{strat}: {len(out['files'][strat]['simple_returns'])} bytes of returns text")
+    path = os.path.join(OUT, name + "_csv.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     holder = {"tickers": []}
     pc, ps = import_reference(holder)
-    which = sys.argv[1:] or ["single", "backtest", "specs", "large", "jorion", "greyserman", "shipped"]
+    which = sys.argv[1:] or ["single", "backtest", "specs", "large", "jorion", "greyserman", "shipped", "csv"]
     conj = ["conjugate_hf_vix_vw", "conjugate_hf_vix_ew"]
     if "single" in which:
         # BASELINE config 1 shapes (k=10, N=60), 4 windows, all intermediates + inputs stored
@@ -195,6 +224,10 @@ def main():
                      8, 30, "weekly", "monthly", 260, 12, 20240011, 170, rf_nan_every=17)
         gen_backtest(pc, holder, "backtest_k6_n9_monthly_weekly", ["conjugate_hf_epu_vw", "jeffreys", "ew"],
                      6, 9, "monthly", "weekly", 300, 9, 20240012, 230)
+    if "csv" in which:
+        # F4: the text of the result files of src/main.py:79-81 for the configs[0] backtest
+        gen_result_csv(pc, holder, "backtest_k10_n60_daily", ["conjugate_hf_vix_vw", "jeffreys", "vw"], 10, 60, "daily",
+                       "daily", 165, 14, 20240001, 65)
     if "jorion" in which:
         # F3: Jorion's Bayes-Stein portfolio (ref:851-895) on single windows and in a backtest
         out = {}

@@ -27,6 +27,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libtangency.so does not export {name}"
     lib.tp_version.restype = ctypes.c_char_p
     assert b"tangency-posterior" in lib.tp_version()
+    import incorporating_different_sources_amd as pkg
+    assert pkg.__version__.encode() in lib.tp_version()          # one version number for the package and the library
     lib.tp_max_assets.restype = ctypes.c_int
     assert lib.tp_max_assets() >= 100
 

@@ -1,7 +1,6 @@
 """Round 3: the one-wave-per-window kernel (csrc/posterior_wave_impl.h) against the multi-wave kernel and the oracle.
--m gpu.  TP_WAVE_KERNEL is read by the library at every launch, so one process can run both kernels."""
-import os
-
+-m gpu.  The kernel choice is a per-handle option (`tp_set_option`; the TP_* environment variables are read once, at
+tp_create), so one process runs both kernels on the default device."""
 import numpy as np
 import pytest
 
@@ -18,13 +17,10 @@ def native():
 
 
 @pytest.fixture()
-def kernel_choice():
-    old = os.environ.get("TP_WAVE_KERNEL")
-    yield lambda v: os.environ.__setitem__("TP_WAVE_KERNEL", v)
-    if old is None:
-        os.environ.pop("TP_WAVE_KERNEL", None)
-    else:
-        os.environ["TP_WAVE_KERNEL"] = old
+def kernel_choice(native):
+    dev = native.default_device()
+    yield lambda v: dev.set_option("wave_kernel", int(v))
+    dev.set_option("wave_kernel", -1)
 
 
 def _run(native, strat, k, N, inp, **extra):
@@ -95,25 +91,21 @@ def test_wave_kernel_flags_a_singular_window(native, kernel_choice):
 
 def test_large_k_path_flags_singular_windows_and_agrees_across_its_kernel_forms(native):
     """Large-k path (k >= 240): rank-deficient windows are flagged by the one-wave diagonal-block kernel; and its one-wave
-    kernels (Gram super-tile, diagonal block, fused update + TRSM) give the 4-wave kernels' weights (TP_TILED_WAVE=0,
-    TP_TILED_FUSE=0) to rounding on well-posed windows."""
+    kernels (Gram super-tile, diagonal block, fused update + TRSM) give the 4-wave kernels' weights (options tiled_wave = 0,
+    tiled_fuse = 0) to rounding on well-posed windows."""
     k, N = 300, 120
     inp = synthetic.make_kernel_inputs(k, N, 5, seed=11)
     _, s, _ = _run(native, "jeffreys", k, N, inp)                      # 119 rows, 300 assets: singular
     assert (s != 0).all()
     k, N = 260, 700
     inp = synthetic.make_kernel_inputs(k, N, 6, seed=12, hf_days=4)
-    old = {v: os.environ.get(v) for v in ("TP_TILED_WAVE", "TP_TILED_FUSE")}
+    dev = native.default_device()
     try:
-        os.environ.pop("TP_TILED_WAVE", None); os.environ.pop("TP_TILED_FUSE", None)
+        dev.set_option("tiled_wave", -1).set_option("tiled_fuse", -1)
         w_new, s_new, _ = _run(native, "conjugate", k, N, inp)
-        os.environ["TP_TILED_WAVE"] = "0"; os.environ["TP_TILED_FUSE"] = "0"
+        dev.set_option("tiled_wave", 0).set_option("tiled_fuse", 0)
         w_old, s_old, _ = _run(native, "conjugate", k, N, inp)
     finally:
-        for v, x in old.items():
-            if x is None:
-                os.environ.pop(v, None)
-            else:
-                os.environ[v] = x
+        dev.set_option("tiled_wave", -1).set_option("tiled_fuse", -1)
     assert (s_new == 0).all() and (s_old == 0).all()
     np.testing.assert_allclose(w_new, w_old, rtol=0, atol=1e-11)

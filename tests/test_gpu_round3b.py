@@ -1,0 +1,182 @@
+"""Round 3 (-m gpu): gaps the round-2 verdict and advice named.
+
+* a non-finite panel row in the contiguous (shared-Gram) layout poisons exactly the windows that contain it;
+* the reference golden at k = 200 - the multi-wave / two-wave kernels' own range - on the GPU;
+* configs[2] at its full 50,000 windows: determinism + sampled oracle windows (item 6c);
+* a synchronous upload, a run, then an asynchronous upload of the same batch: the copy waits for the launch;
+* handle options replace the environment switches (item 3)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from incorporating_different_sources_amd import synthetic
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+WTOL = dict(rtol=0, atol=1e-10)
+
+
+@pytest.fixture(scope="module")
+def native():
+    from incorporating_different_sources_amd import _native
+    return _native
+
+
+@pytest.mark.parametrize("k,N,hf_days", [(20, 60, 1), (100, 250, 1), (150, 200, 2), (260, 300, 4)])
+@pytest.mark.parametrize("bad", [np.nan, np.inf, 1e200])
+def test_a_non_finite_row_poisons_only_the_windows_that_contain_it(native, k, N, hf_days, bad):
+    """Rolling windows over one panel take their whole 16-row blocks from sliding block-window sums.
+    One NaN / Inf / overflowing value in panel row r must flag the windows [r - n_r + 1, r] and nobody else: round 2's
+    slide (add the entering block, subtract the leaving one) kept Inf - Inf = NaN in every later position of its run.
+    Statuses equal the no-sharing path's (TP_FLAG_NO_SHARED_GRAM) window by window; clean windows agree to 1e-12."""
+    W = 400
+    inp = synthetic.make_kernel_inputs(k, N, W, seed=4242 + k, hf_days=hf_days)
+    n_r = inp["n_r"]
+    panel = inp["panel"].copy()
+    r_bad, c_bad = n_r + 37, min(3, k - 1)
+    panel[r_bad, c_bad] = bad
+    kw = dict(panel=panel, start=inp["start"], n_r=n_r, hf_panel=inp["hf_panel"], hf_start=inp["hf_start"], m=inp["m"],
+              w0=inp["w0"], n0=inp["n0"])
+    dev = native.default_device()
+    b = native.Batch(dev, "conjugate", k, N, n_r, 5.0, W, inp["m"])
+    try:
+        b.upload(**{key: val for key, val in kw.items() if key not in ("n_r", "m")})
+        assert b.shared_gram_blocks() > 0                                  # the layout under test
+        b.run()
+        w_sh, s_sh, _ = b.download()
+    finally:
+        b.close()
+    w_no, s_no, _ = native.posterior_batch("conjugate", k, N, 5.0, flags=native.FLAG_NO_SHARED_GRAM, **kw)
+    contains = (inp["start"] <= r_bad) & (r_bad < inp["start"] + n_r)
+    assert contains.sum() == n_r
+    assert (s_sh[contains] != 0).all() and (s_no[contains] != 0).all()
+    assert (s_sh[~contains] == 0).all(), np.flatnonzero((s_sh != 0) & ~contains)[:10]
+    assert np.array_equal(s_sh != 0, s_no != 0)
+    np.testing.assert_allclose(w_sh[~contains], w_no[~contains], rtol=0, atol=1e-12)
+    clean = dict(kw, panel=inp["panel"])
+    w_clean, s_clean, _ = native.posterior_batch("conjugate", k, N, 5.0, **clean)
+    np.testing.assert_allclose(w_sh[~contains], w_clean[~contains], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("strat", ["conjugate_hf_vix_vw", "conjugate_hf_vix_ew", "jeffreys"])
+@pytest.mark.parametrize("choice", [-1, 0])
+def test_k200_matches_reference_golden(native, strat, choice):
+    """`single_k200_n250`: outputs of the unmodified reference at k = 200 (13 tiles per side: above the one-wave kernel's
+    range) - conjugate vw / ew at the flat 1e-10, and the Jeffreys parity SURVEY section 8(d) asks for at a shape where
+    J is invertible (k <= N - 2).  Jeffreys at k = 200 over 249 rows has a rank margin of 49: the reference's own LU
+    inverse is only good to ~1e-8 relative there (tests/test_oracle_golden.py uses the same bound for the oracle).
+    choice: -1 = the kernel the library picks for this size, 0 = the multi-wave kernel."""
+    g = np.load(os.path.join(GOLDEN, "single_k200_n250.npz"))
+    k, N, hf_days, seed = int(g["k"]), int(g["N"]), int(g["hf_days"]), int(g["seed"])
+    inp = synthetic.make_kernel_inputs(k, N, 1, seed, hf_days=hf_days)
+    n_r, m = inp["n_r"], inp["m"]
+    P = 100.0 * np.exp(np.concatenate([np.zeros((1, k)), np.cumsum(inp["panel"][:n_r], axis=0)]))
+    X = oracle.excess_log_returns_from_prices(P)
+    H = 50.0 * np.exp(np.concatenate([np.zeros((1, k)), np.cumsum(inp["hf_panel"][:m], axis=0)]))
+    Y = oracle.excess_log_returns_from_prices(H)
+    dev = native.default_device()
+    dev.set_option("wave_kernel", choice)
+    try:
+        if strat == "jeffreys":
+            wts, status, _ = native.posterior_batch("jeffreys", k, N, 5.0, panel=X, start=np.zeros(1, np.int64), n_r=n_r)
+            tol = dict(rtol=1e-7, atol=1e-9)
+        else:
+            order = g[f"w0_{strat}_order"].astype(np.int32)
+            wts, status, aux = native.posterior_batch(
+                "conjugate", k, N, 5.0, panel=X, start=np.zeros(1, np.int64), n_r=n_r, hf_panel=Y,
+                hf_start=np.zeros(1, np.int64), m=m, w0=g[f"w0_{strat}_w0"][None, :],
+                n0=np.array([float(g[f"w0_{strat}_n0"])]), col_idx=order[None, :])
+            tol = WTOL
+            assert aux[0, 2] == pytest.approx(float(g[f"w0_{strat}_c"]), rel=1e-11)
+            assert aux[0, 4] == pytest.approx(float(g[f"w0_{strat}_q1"]), rel=1e-8)
+    finally:
+        dev.set_option("wave_kernel", -1)
+    assert status[0] == 0
+    np.testing.assert_allclose(wts[0], g[f"w0_{strat}_weights"], **tol)
+
+
+def test_configs2_at_its_full_window_count(native):
+    """BASELINE configs[2] as stated: k = 500, N = 250, m = 389, 50,000 windows on one GPU - determinism (two runs
+    bit-identical), every status OK, 8 sampled windows against the oracle at the flat 1e-10.  The intraday panel wraps
+    after 8,192 days (2.5 GB of host memory instead of 15.6 GB; a window's rows are the same kind of data either way -
+    what the wrap does to the HBM footprint is measured in DESIGN section 5, not here)."""
+    shp = synthetic.config_shapes(3)
+    W = 50_000
+    inp = synthetic.make_kernel_inputs(shp["k"], shp["N"], W, seed=shp["seed"], hf_days=shp["hf_days"], hf_period=8192)
+    kw = dict(panel=inp["panel"], start=inp["start"], hf_panel=inp["hf_panel"], hf_start=inp["hf_start"], w0=inp["w0"],
+              n0=inp["n0"])
+    dev = native.default_device()
+    b = native.Batch(dev, "conjugate", shp["k"], shp["N"], shp["n_r"], 5.0, W, shp["m"])
+    try:
+        b.upload(**kw)
+        b.run()
+        w1, s1, a1 = b.download()
+        b.run()
+        w2, s2, a2 = b.download()
+    finally:
+        b.close()
+    assert (s1 == 0).all() and np.isfinite(w1).all()
+    assert np.array_equal(w1, w2) and np.array_equal(a1, a2)
+    sample = np.unique(np.concatenate([[0, W - 1], np.random.default_rng(3).integers(0, W, 6)]))
+    sub = {key: (val[sample] if key in ("start", "hf_start", "w0", "n0") else val) for key, val in kw.items()}
+    ref, rstat, raux = oracle.posterior_batch_c("conjugate", shp["k"], shp["N"], 5.0, n_r=shp["n_r"], m=shp["m"], **sub)
+    assert (rstat == 0).all()
+    np.testing.assert_allclose(w1[sample], ref, **WTOL)
+    np.testing.assert_allclose(a1[sample, :6], raux[:, :6], rtol=1e-11, atol=1e-14)
+
+
+def test_async_upload_after_a_run_waits_for_the_launch(native):
+    """tp_batch_upload (synchronous), tp_batch_run, tp_batch_upload_async on the SAME batch: the copy stream
+    must not overwrite the panels the running launch still reads.  The end of every launch is an event the next
+    asynchronous upload waits for; results of run 1 are those of inputs 1, of run 2 those of inputs 2."""
+    k, N, W = 100, 250, 6000
+    a = synthetic.make_kernel_inputs(k, N, W, seed=501)
+    c = synthetic.make_kernel_inputs(k, N, W, seed=502)
+    names = ("panel", "start", "hf_panel", "hf_start", "w0", "n0")
+    ref_a, _, _ = native.posterior_batch("conjugate", k, N, 5.0, n_r=a["n_r"], m=a["m"], **{n: a[n] for n in names})
+    ref_c, _, _ = native.posterior_batch("conjugate", k, N, 5.0, n_r=c["n_r"], m=c["m"], **{n: c[n] for n in names})
+    pinned_c = {n: native.pinned_copy(c[n]) for n in names}
+    dev = native.default_device()
+    b = native.Batch(dev, "conjugate", k, N, a["n_r"], 5.0, W, a["m"])
+    try:
+        b.upload(**{n: a[n] for n in names})
+        for _ in range(3):
+            b.run()                                   # three launches queued: the kernel stream is busy ...
+        b.upload_async(**pinned_c)                    # ... while the copies are queued on the copy stream
+        w_a, s_a, _ = b.download()                    # results of the launches that read inputs A
+        b.run()
+        w_c, s_c, _ = b.download()
+    finally:
+        b.close()
+    assert np.array_equal(w_a, ref_a) and np.array_equal(w_c, ref_c)
+
+
+def test_options_are_per_handle_and_the_environment_is_read_once(native, monkeypatch):
+    """kernel-selection switches live on the handle.  Changing the environment after a Device exists
+    changes nothing for it; `set_option` does; an unknown option is an error."""
+    k, N, W = 100, 120, 64
+    inp = synthetic.make_kernel_inputs(k, N, W, seed=9)
+    kw = dict(panel=inp["panel"], start=inp["start"], n_r=inp["n_r"])
+    dev = native.Device(0)
+    try:
+        native.posterior_batch("jeffreys", k, N, 5.0, device=dev, **kw)
+        one_wave = dev.last_launch()["block"]
+        monkeypatch.setenv("TP_WAVE_KERNEL", "0")
+        native.posterior_batch("jeffreys", k, N, 5.0, device=dev, **kw)
+        assert dev.last_launch()["block"] == one_wave == 64              # the environment is not consulted at launch
+        dev.set_option("wave_kernel", 0)
+        native.posterior_batch("jeffreys", k, N, 5.0, device=dev, **kw)
+        assert dev.last_launch()["block"] == 256                        # the multi-wave kernel: 4 waves per window
+        with pytest.raises(native.TangencyError):
+            dev.set_option("no_such_switch", 1)
+        dev2 = native.Device(0)                                          # a NEW handle reads the environment
+        try:
+            native.posterior_batch("jeffreys", k, N, 5.0, device=dev2, **kw)
+            assert dev2.last_launch()["block"] == 256
+        finally:
+            dev2.close()
+    finally:
+        dev.close()

@@ -235,8 +235,9 @@ def _conj_spec(strat, scaling=1, gamma=5):
 
 
 def test_weights_shard_over_all_devices_of_the_process(pc, monkeypatch):
-    """`backtest_portfolio`'s device batch uses every visible GPU of the ONE process - here two
-    stand-in devices; sharded == unsharded bit for bit, one gather."""
+    """`backtest_portfolio`'s device batch can use every visible GPU of the ONE process - here two
+    stand-in devices; sharded == unsharded bit for bit, one gather.  Since round 3 the route is opt-in
+    (`use_device_group` / TP_SHARD=1): without it two visible devices still mean one device."""
     md, _ = synthetic.make_market_data(n_tickers=8, n_days=90, seed=13)
     days = [pd.Timestamp(d) for d in md["stock_prices_df"].index[30:]]
     one = _OracleNative(1)
@@ -245,6 +246,12 @@ def test_weights_shard_over_all_devices_of_the_process(pc, monkeypatch):
     two = _OracleNative(2)
     monkeypatch.setattr(pc, "_native", two)
     monkeypatch.setattr(pc, "SHARD_MIN_WINDOWS", 8)
+    from incorporating_different_sources_amd import batch
+    w0, _, _, _ = pc._weights_for_dates(days, _conj_spec("conjugate_hf_vix_vw"), md)     # not opted in: one device
+    assert two.calls == [len(days)] and two.default_group().gathers == 0 and np.array_equal(w0, w1)
+    two.calls.clear()
+    monkeypatch.setattr(pc, "_shard_opt_in", True)
+    monkeypatch.setattr(pc, "_shard_group", None)
     w2, labels2, cols2, caps2 = pc._weights_for_dates(days, _conj_spec("conjugate_hf_vix_vw"), md)
     assert np.array_equal(w1, w2) and labels1 == labels2 and np.array_equal(cols1, cols2)
     assert two.default_group().gathers == 1 and two.calls == [] and one.calls == [len(days)]
