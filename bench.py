@@ -30,7 +30,16 @@ sys.path.insert(0, REPO)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense FP64 matrix peak: 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+CLOCK_HZ = 2.4e9               # nominal shader clock the peak is quoted at
+N_SIMD = 1024                  # 256 CUs x 4 SIMDs
+FLOPS_PER_MFMA_F64 = 2048      # v_mfma_f64_16x16x4_f64: 16 x 16 x 4 multiply-adds
 WINDOWS_PER_RANK = {4: 25_000, 5: 125_000}     # configs[3] / configs[4]: 200k resp. 1M windows over 8 GPUs
+HF_PANEL_BUDGET_BYTES = 24e9   # host bytes of the synthetic intraday panel per rank above which it wraps (hf_period)
+# the unmodified reference, one window per call, measured in the survey container (8 cores)
+REFERENCE_AS_SHIPPED = {100: {"windows_per_s": 29.0, "check_off_windows_per_s": 74.0},
+                        10: {"windows_per_s": 52.0, "check_off_windows_per_s": 84.0},
+                        500: {"windows_per_s": 5.8, "check_off_windows_per_s": 33.0},
+                        1000: {"windows_per_s": 1.0, "check_off_windows_per_s": 15.0}}
 
 
 def alg_bytes_per_window(k, n_r, m, conj=True):
@@ -43,14 +52,11 @@ def alg_flops_per_window(k, n_r, m, conj=True):
     return ((n_r + m) * k * (k + 1) + k ** 3 / 3 + 6 * k ** 2) if conj else (n_r * k * (k + 1) + k ** 3 / 3 + 5 * k ** 2)
 
 
-def register_tile_kernel(k):
-    """Which of the two register-tile kernels the library runs for k assets (csrc/posterior_fused.hip,
-    tp_use_wave_kernel): one wavefront per window up to 9 tiles per side, the multi-wave kernel above;
-    TP_WAVE_KERNEL=0/1 in the environment overrides it for A/B measurements."""
-    nt = (k + 1 + 15) // 16
-    env = os.environ.get("TP_WAVE_KERNEL", "")
-    wave = (int(env) != 0) if env else nt <= 9
-    return "posterior_wave_kernel (one wavefront per window)" if wave and nt <= 9 else "posterior_fused_kernel"
+def register_tile_kernel(launch):
+    """Which register-tile kernel the library ran, from the launch geometry it reports (`tp_last_launch`): one wavefront
+    per window (64 threads), two (128, csrc/posterior_wave2_impl.h) or the multi-wave kernel."""
+    return {64: "posterior_wave_kernel (one wavefront per window)",
+            128: "posterior_wave2_kernel (two wavefronts per window)"}.get(launch["block"], "posterior_fused_kernel")
 
 
 def parse_args():
@@ -67,6 +73,16 @@ def parse_args():
     ap.add_argument("--rehearse-gather", action="store_true",
                     help="N=1 only: run the N>1 step (RCCL gather on the second stream + its verification) on a "
                          "one-rank communicator")
+    ap.add_argument("--layout", default="contiguous", choices=["contiguous", "no-shared-gram", "index"],
+                    help="data layout of the TIMED batch: contiguous rolling windows (default: the headline; the daily "
+                         "Gram of whole row blocks comes from sums all windows share), the same without sharing "
+                         "(TP_FLAG_NO_SHARED_GRAM), or the index layout (row_idx / col_idx / rf_adj / hf_row_idx: what "
+                         "batch.pack_windows produces for real backtests with changing universes, ref:611-658, 149-156)")
+    ap.add_argument("--no-general-layout", action="store_true",
+                    help="skip the no-shared-gram and index-layout legs that follow the timed region (N=1 only)")
+    ap.add_argument("--hf-period", type=int, default=-1,
+                    help="days after which the synthetic intraday panel wraps (0: never; default: never unless the panel "
+                         "would exceed 24 GB of host memory per rank)")
     ap.add_argument("--rehearse-world", type=int, default=0,
                     help="run the host logic of this many ranks on however many GPUs the box has (ranks share devices, "
                          "no RCCL, host gather): a rehearsal, never a measurement")
@@ -162,8 +178,15 @@ def worker(args):
     W = args.windows or (WINDOWS_PER_RANK.get(config, shp["W"]) if cp.world > 1 else min(shp["W"], WINDOWS_PER_RANK.get(config, shp["W"])))
     conj = args.strategy == "conjugate"
     # rank r owns its own windows (weak scaling): an independent synthetic panel per rank
+    # intraday panel: one row block per window day, un-wrapped whenever it fits the host (a wrapped panel is a
+    # friendlier HBM footprint than SURVEY section 8(d)'s shapes)
+    hf_period = args.hf_period
+    if hf_period < 0:
+        full_bytes = (W + shp["hf_days"] - 1) * synthetic.BARS_PER_DAY * k * 8.0
+        hf_period = 0 if (full_bytes <= HF_PANEL_BUDGET_BYTES or not conj) else \
+            max(1, int(HF_PANEL_BUDGET_BYTES / (synthetic.BARS_PER_DAY * k * 8.0)) - shp["hf_days"])
     inp = synthetic.make_kernel_inputs(k, N, W, seed=shp["seed"] + 1000 * cp.rank, hf_days=shp["hf_days"],
-                                       hf_period=2048 if shp["hf_days"] > 1 else 0)
+                                       hf_period=hf_period)
 
     dev = _native.Device(cp.local_rank % ndev if rehearsal else cp.local_rank)
     gather_mode, rccl_ranks = "none", None
@@ -177,11 +200,28 @@ def worker(args):
     elif cp.world > 1:
         gather_mode = "host-tcp (rehearsal: ranks share devices, no RCCL)"
 
-    batch = dev.batch(args.strategy, k, N, n_r, 5.0, W, m if conj else 0)
     kw = dict(panel=inp["panel"], start=inp["start"])
     if conj:
         kw.update(hf_panel=inp["hf_panel"], hf_start=inp["hf_start"], w0=inp["w0"], n0=inp["n0"])
-    batch.upload(**kw)
+
+    def make_batch(layout):
+        """The same W windows in one of the three layouts (all resident in HBM before anything is timed)."""
+        flags = _native.FLAG_NO_SHARED_GRAM if layout == "no-shared-gram" else 0
+        b = dev.batch(args.strategy, k, N, n_r, 5.0, W, m if conj else 0, flags=flags)
+        if layout != "index":
+            b.upload(**kw)
+            return b
+        # identity index arrays: exactly the windows of the contiguous layout, addressed the way batch.pack_windows
+        # addresses real ones (explicit rows, gathered columns, a per-row risk-free adjustment)
+        ikw = dict(panel=inp["panel"], row_idx=(inp["start"][:, None] + np.arange(n_r)[None, :]).astype(np.int32),
+                   col_idx=np.tile(np.arange(k, dtype=np.int32), (W, 1)), rf_adj=np.zeros((W, n_r)))
+        if conj:
+            ikw.update(hf_panel=inp["hf_panel"], hf_row_idx=(inp["hf_start"][:, None] + np.arange(m)[None, :]).astype(np.int32),
+                       w0=inp["w0"], n0=inp["n0"])
+        b.upload(**ikw)
+        return b
+
+    batch = make_batch(args.layout)
     h2d_ms = dev.last_timing()["h2d_ms"]
     shared_blocks = batch.shared_gram_blocks()
 
@@ -199,17 +239,24 @@ def worker(args):
     dev.synchronize()
     cp.barrier()
     t0 = time.perf_counter()
-    if cp.world == 1:
-        dev.region_begin()
+    dev.region_begin()                   # HIP events on the kernel stream: the region, and one pair per step's launches
     for _ in range(args.steps):
         step()
-    region_ms = dev.region_end() if cp.world == 1 else None
+    region_ms = dev.region_end()
     dev.synchronize()
     cp.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = cp.max(elapsed)
     tim = dev.last_timing()
-    kernel_ms = (region_ms / args.steps) if region_ms is not None else tim["kernel_ms"]
+    steps_ms = np.sort(dev.region_steps())
+    # N = 1: the region holds nothing but the steps' kernels back to back; N > 1: the kernels only (the gather runs on
+    # its own stream), so the mean of the per-step brackets
+    kernel_ms = (region_ms / args.steps) if cp.world == 1 else float(steps_ms.mean()) if len(steps_ms) else tim["kernel_ms"]
+    step_stats = None
+    if len(steps_ms):
+        step_stats = {"n": int(len(steps_ms)), "median": float(np.median(steps_ms)), "min": float(steps_ms[0]),
+                      "max": float(steps_ms[-1]), "p90": float(steps_ms[int(0.9 * (len(steps_ms) - 1))]),
+                      "source": "one HIP-event pair per step on the kernel stream (tp_region_steps)"}
 
     weights, status, aux = batch.download()
     d2h_ms = dev.last_timing()["d2h_ms"]
@@ -247,7 +294,7 @@ def worker(args):
     okw = (status[:ns] == 0) & (rstat == 0)
     parity = cp.max(float(np.abs(weights[:ns][okw] - ref[okw]).max()) if okw.any() else 0.0)
 
-    cpu = cpu1 = None
+    cpu = cpu1 = cpu16 = None
     if cp.rank == 0 and not args.no_cpu_baseline:
         # the oracle's C restatement (OpenMP over windows) on a bounded sample of the same workload
         def time_cpu(threads, sample, budget_s):
@@ -261,11 +308,50 @@ def worker(args):
             return {"value": sample * reps / cdt, "unit": "windows/s", "cores": threads, "kind": "port",
                     "sample": f"{reps} x {sample} windows of the same workload (oracle/tangency_oracle.c, OpenMP over "
                               f"windows), {cdt:.2f} s wall"}
-        # a one-GPU box shares its host: 16 cores is this pool's per-GPU CPU share
-        threads = min(oracle.c_num_threads(), len(os.sched_getaffinity(0)), 16)
+        # all host cores and one core; the 16-thread leg is this pool's per-GPU CPU share
         per_thread = max(8, int(2.5e9 / alg_flops_per_window(k, n_r, m, conj)))      # ~1 s of one core
-        cpu = time_cpu(threads, min(W, per_thread * threads), 1.0)
-        cpu1 = time_cpu(1, min(W, per_thread), 1.0)
+        all_cores = max(1, min(oracle.c_num_threads(), len(os.sched_getaffinity(0))))
+        cpu = time_cpu(all_cores, min(W, per_thread * all_cores), 2.0)
+        cpu16 = time_cpu(min(16, all_cores), min(W, per_thread * min(16, all_cores)), 1.5) if all_cores > 16 else cpu
+        cpu1 = time_cpu(1, min(W, per_thread), 1.5)
+        shipped = REFERENCE_AS_SHIPPED.get(k)
+        cpu["reference_as_shipped"] = None if shipped is None or not conj else dict(
+            shipped, cores=8, unit="windows/s", source="BASELINE.md section 2: the unmodified reference "
+            "(calculate_conjugate_hf_mcm_portfolio, one window per call) in the survey container; not re-measured here "
+            "(the reference's Python does not travel to the GPU box)")
+
+    # General layouts (N = 1, after the timed region, same windows): the headline's contiguous layout lets every window
+    # take its whole 16-row blocks from Gram sums all windows share; a real backtest (changing universes ref:611-658,
+    # resampled windows ref:149-156) arrives in the index layout, which pushes every row through the MFMAs.
+    general = None
+    if cp.world == 1 and not args.no_general_layout and args.layout == "contiguous":
+        general = {}
+        for layout in ("no-shared-gram", "index"):
+            gb = make_batch(layout)
+            gsteps = max(3, min(args.steps, 20))
+            for _ in range(2):
+                gb.run()
+            dev.synchronize()
+            g0 = time.perf_counter()
+            dev.region_begin()
+            for _ in range(gsteps):
+                gb.run()
+            g_ms = dev.region_end() / gsteps
+            dev.synchronize()
+            g_wall = (time.perf_counter() - g0) / gsteps
+            gs = np.sort(dev.region_steps())
+            gw, gst, _ = gb.download(want_aux=False)
+            g_launch = dev.last_launch()
+            g_tf = alg_flops_per_window(k, n_r, m, conj) * W / (g_ms * 1e-3) / 1e12
+            general[layout.replace("-", "_")] = {
+                "windows_per_s": W / g_wall, "kernel_ms": g_ms, "step_ms_median": float(np.median(gs)) if len(gs) else None,
+                "steps": gsteps, "shared_gram_row_blocks": gb.shared_gram_blocks(),
+                "roofline_frac": g_tf / FP64_MFMA_PEAK_TFLOPS, "achieved_tflops": g_tf,
+                "kernel": register_tile_kernel(g_launch) if k <= 239 else "tiled pipeline",
+                "max_abs_diff_vs_headline": float(np.abs(gw - weights).max()),
+                "windows_with_nonzero_status": int((gst != 0).sum()),
+                "executed": executed_from_pmc(layout, k, W, args.strategy, g_ms)}
+            gb.close()
 
     # PCIe-inclusive legs (never `value`): host buffers in, host buffers out
     e2e = None
@@ -277,7 +363,8 @@ def worker(args):
     traffic = None
     try:
         pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
-        if f"k={k}," in pmc["workload"] and f"{W} windows" in pmc["workload"] and args.strategy in pmc["workload"]:
+        if (f"k={k}," in pmc["workload"] and f"{W} windows" in pmc["workload"] and args.strategy in pmc["workload"]
+                and args.layout == "contiguous"):
             traffic = pmc["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
@@ -307,20 +394,31 @@ def worker(args):
                                    + (f" (m={m} intraday returns, VIX-style n0)" if conj else ""),
                        "k": k, "N": N, "n_r": n_r, "m": m if conj else 0, "windows_per_gpu": W,
                        "strategy": args.strategy, "parallelism": f"windows sharded x{cp.world}",
+                       "layout": args.layout, "hf_period_days": hf_period,
                        "shared_gram_row_blocks": shared_blocks,
                        "gather": gather_mode, "rccl_ranks": rccl_ranks, "gather_verified": gathered_ok,
                        "rehearsal": rehearsal, "seed": shp["seed"]},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tf / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "frac": ach_tf / FP64_MFMA_PEAK_TFLOPS,
+                         # what `frac` is: SURVEY section 8(d)'s ALGORITHMIC flops (every window its own full Grams) over the
+                         # measured time.  With shared Gram sums the kernels EXECUTE fewer flops than that, so this is an
+                         # algorithmic-equivalent rate, not matrix-pipe utilisation - `executed` carries that
+                         "frac_kind": "algorithmic-equivalent (shared Gram sums: executed flops < algorithmic flops)"
+                                      if shared_blocks else "algorithmic flops; every row of every window goes through the MFMAs",
+                         "executed": executed_from_pmc(args.layout, k, W, args.strategy, kernel_ms),
+                         "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes)" if traffic else None,
-                         "kernel": (register_tile_kernel(k) + (" (+ block_gram_kernel and tp_window_sums_kernel in front of it, every step)" if shared_blocks else ""))
+                         "kernel": (register_tile_kernel(launch) + (" (+ block_gram_kernel and tp_window_sums_kernel in front of it, every step)" if shared_blocks else ""))
                                    if k <= 239 else "tiled pipeline (prior + prefix + gram + diag / TRSM / SYRK + solve)",
                          "kernel_ms": kernel_ms,
+                         "step_ms": step_stats,
                          "alg_flops_per_window": alg_flops_per_window(k, n_r, m, conj),
                          "alg_bytes_per_window": alg_bytes_per_window(k, n_r, m, conj)},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": ach_gbs / HBM_PEAK_GBS},
+            "general_layout": general,
             "cpu_baseline": cpu,
+            "cpu_baseline_16t": cpu16,
             "cpu_baseline_1t": cpu1,
             "end_to_end": e2e,
             "end_to_end_windows_per_s": e2e["pinned_windows_per_s"] if e2e else None,
@@ -336,6 +434,28 @@ def worker(args):
     batch.close()
     dev.close()
     cp.close()
+
+
+def executed_from_pmc(layout, k, W, strategy, kernel_ms):
+    """Executed-work fractions of one step from the committed rocprofv3 --pmc passes of the same workload and layout
+    (profiles/pmc_traffic.json "sq_counters"; counters cannot be read from inside this process): the flops the MFMA
+    instructions actually performed over the measured time, and the share of SIMD-cycles the matrix pipe was busy during
+    the profiled launches.  None when no pass of this workload / layout is committed."""
+    try:
+        pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+        ent = pmc["sq_counters"][layout]
+        if ent["k"] != k or ent["windows"] != W or ent["strategy"] != strategy:
+            return None
+        insts, busy, pmc_ms = ent["SQ_INSTS_MFMA"], ent["SQ_VALU_MFMA_BUSY_CYCLES"], ent["kernel_ms_under_pmc"]
+        ex_tf = insts * FLOPS_PER_MFMA_F64 / (kernel_ms * 1e-3) / 1e12
+        return {"mfma_instructions_per_step": insts, "executed_tflops": ex_tf,
+                "executed_mfma_frac": ex_tf / FP64_MFMA_PEAK_TFLOPS,
+                "mfma_pipe_busy_frac": busy / (N_SIMD * pmc_ms * 1e-3 * CLOCK_HZ),
+                "source": ent.get("source", "profiles/pmc_traffic.json"),
+                "note": "SQ_INSTS_MFMA x 2048 flop / this run's kernel time / peak; SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
+                        "the profiled kernel time x 2.4 GHz)"}
+    except Exception:
+        return None
 
 
 def end_to_end(dev, _native, strategy, k, N, n_r, m, W, conj, kw, expect):

@@ -214,6 +214,10 @@ int tp_last_timing(tp_handle_t h, double* kernel_ms, double* h2d_ms, double* d2h
  * timed region): begin records an event, end records another, waits for it and returns the span. */
 int tp_region_begin(tp_handle_t h);
 int tp_region_end(tp_handle_t h, double* ms);
+/* Kernel time of every tp_batch_run inside the last region (each launch is bracketed by its own pair of HIP events on
+ * the kernel stream; nothing waits between the steps; at most 512 steps are kept): bench.py's per-step median.
+ * step_ms may be NULL (n_steps only). */
+int tp_region_steps(tp_handle_t h, double* step_ms, int capacity, int* n_steps);
 /* Launch geometry of the most recent tp_batch_run: grid size, threads per workgroup, LDS bytes,
  * 16-column tile count per side. */
 int tp_last_launch(tp_handle_t h, int* grid, int* block, int* lds_bytes, int* ntile);

@@ -43,7 +43,7 @@ EXPORTS = [
     "tp_host_alloc", "tp_host_free", "tp_batch_set_rhs", "tp_batch_set_shift", "tp_batch_keep_rhs",
     "tp_batch_download_rhs", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1", "tp_batch_download_matrix",
     "tp_batch_debug_stamps", "tp_batch_destroy", "tp_posterior_batch", "tp_synchronize", "tp_last_timing",
-    "tp_region_begin", "tp_region_end", "tp_last_launch", "tp_comm_unique_id", "tp_comm_init", "tp_comm_destroy",
+    "tp_region_begin", "tp_region_end", "tp_region_steps", "tp_last_launch", "tp_comm_unique_id", "tp_comm_init", "tp_comm_destroy",
     "tp_comm_count", "tp_comm_init_all", "tp_group_gather",
     "tp_batch_gather", "tp_batch_gather_async", "tp_batch_download_gathered",
 ]
@@ -113,6 +113,7 @@ def _load():
     lib.tp_last_timing.argtypes = [c_void_p] + [POINTER(c_double)] * 4
     lib.tp_region_begin.argtypes = [c_void_p]
     lib.tp_region_end.argtypes = [c_void_p, POINTER(c_double)]
+    lib.tp_region_steps.argtypes = [c_void_p, POINTER(c_double), c_int, POINTER(c_int)]
     lib.tp_last_launch.argtypes = [c_void_p] + [POINTER(c_int)] * 4
     lib.tp_comm_unique_id.argtypes = [c_void_p]
     lib.tp_comm_init.argtypes = [c_void_p, c_void_p, c_int, c_int]
@@ -325,6 +326,15 @@ class Device:
         ms = c_double()
         self._check(lib.tp_region_end(self._h, ctypes.byref(ms)))
         return ms.value
+
+    def region_steps(self) -> np.ndarray:
+        """Kernel milliseconds of every `run` inside the last region_begin / region_end bracket (HIP events per launch)."""
+        n = c_int()
+        self._check(lib.tp_region_steps(self._h, None, 0, ctypes.byref(n)))
+        out = np.empty(n.value, dtype=np.float64)
+        if n.value:
+            self._check(lib.tp_region_steps(self._h, _ptr(out, c_double), n.value, ctypes.byref(n)))
+        return out
 
     # ---- RCCL -------------------------------------------------------------------------------
     @staticmethod

@@ -32,39 +32,50 @@ hipError_t tp_fused_launch(const tp_kargs_t& a, int grid, hipStream_t stream, tp
 }
 
 // Block-window sums of the shared daily Gram: Q_L[b0] = G[b0] + ... + G[b0 + L - 1] for every block position b0 and each
-// block count L the batch needs.  Elementwise (16 bytes per thread): a thread owns one pair of doubles for a run of
-// TP_WINSUM_RUN consecutive positions - the first sum of the run is taken in full (ascending blocks), the following ones
-// slide (add the entering block, subtract the leaving one), so the rounding of Q_L[b0] depends on the panel and on b0
-// alone.  HBM / L2-bound: reads 2 slots and writes 1 per position.
-// Non-finite panel values (a NaN row; an infinite price ratio that the front-end clamps to +-DBL_MAX, whose square
-// overflows) must poison exactly the windows that CONTAIN them: a sliding difference would carry Inf - Inf = NaN into
-// every later position of the run.  So a position whose previous sum is not finite is summed in full again - while the
-// bad block is inside the window that is the same NaN / Inf, once it has left it is the clean sum.
+// block count L the batch needs.  Elementwise (16 bytes per thread).  ADDITIONS ONLY - round 2 slid the sums (add the
+// entering block, subtract the leaving one), and a subtraction carries whatever the leaving block held into every later
+// position of the run: one NaN row, an infinite price ratio (clamped to +-DBL_MAX by the front-end: its square overflows)
+// or merely a huge finite outlier (1e200 x 0.01 = 1e198 absorbs every normal term for good) spoiled windows that do not
+// contain the row.  Now a thread owns one pair of doubles for a group of R = min(L, 16) consecutive positions
+// b0 = g .. g + R - 1 and splits every window at the group's end:
+//     [b0, b0 + L)  =  [b0, g + R)  u  [g + R, g + L)  u  [g + L, b0 + L)
+//                      suffix S[i]     middle M (per group)   prefix P[i]       (b0 = g + i)
+// S runs backwards over the group's own blocks, P forwards over the blocks behind the middle: every block is read once
+// as part of a suffix and once as part of a prefix (the traffic of the sliding form: 2 slot reads + 1 write per position
+// for L <= 16) and Q_L[b0] = (S[i] + M) + P[i] contains the blocks of ITS window and nothing else; its rounding depends on
+// the panel, b0 and L alone.
 typedef double tp_d2 __attribute__((ext_vector_type(2)));
 __global__ void __launch_bounds__(256) tp_window_sums_kernel(const tp_d2* __restrict__ G, tp_d2* __restrict__ Q, int nblk,
                                                              long long slot_pairs, int4 Ls, int n_L) {
+    constexpr int R = TP_WINSUM_RUN;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= slot_pairs) return;
     const int li = blockIdx.z;
     const int L = li == 0 ? Ls.x : li == 1 ? Ls.y : li == 2 ? Ls.z : Ls.w;
+    if (li >= n_L || L < 1) return;
     const int npos = nblk - L + 1;                          // positions b0 with b0 + L <= nblk
-    const int bs = blockIdx.y * TP_WINSUM_RUN;
-    if (li >= n_L || L < 1 || bs >= npos) return;
-    const int be = bs + TP_WINSUM_RUN < npos ? bs + TP_WINSUM_RUN : npos;
-    auto full = [&](int b0) {
-        tp_d2 acc = G[(long long)b0 * slot_pairs + e];
-        for (int b = b0 + 1; b < b0 + L; ++b) acc += G[(long long)b * slot_pairs + e];
-        return acc;
-    };
-    tp_d2 sum = full(bs);
-    tp_d2* out = Q + (long long)li * nblk * slot_pairs;
-    out[(long long)bs * slot_pairs + e] = sum;
-    for (int b0 = bs + 1; b0 < be; ++b0) {
-        if (__builtin_isfinite(sum[0]) && __builtin_isfinite(sum[1]))
-            sum += G[(long long)(b0 + L - 1) * slot_pairs + e] - G[(long long)(b0 - 1) * slot_pairs + e];
-        else
-            sum = full(b0);
-        out[(long long)b0 * slot_pairs + e] = sum;
+    const int Rr = L < R ? L : R;                           // group length
+    const int g = blockIdx.y * Rr;
+    if (g >= npos) return;
+    const tp_d2* Ge = G + e;
+    tp_d2* out = Q + (long long)li * nblk * slot_pairs + e;
+    tp_d2 S[R];
+    tp_d2 run = tp_d2{0.0, 0.0};
+#pragma unroll
+    for (int i = R - 1; i >= 0; --i) {                      // suffix sums of the group's own blocks (g + i <= nblk - 1)
+        if (i < Rr) run += Ge[(long long)(g + i) * slot_pairs];
+        S[i] = run;
+    }
+    tp_d2 M = tp_d2{0.0, 0.0};
+    for (int b = g + Rr; b < g + L; ++b) M += Ge[(long long)b * slot_pairs];      // empty for L <= 16
+    out[(long long)g * slot_pairs] = S[0] + M;
+    tp_d2 P = tp_d2{0.0, 0.0};
+#pragma unroll
+    for (int i = 1; i < R; ++i) {
+        if (i < Rr && g + i < npos) {
+            P += Ge[(long long)(g + L + i - 1) * slot_pairs];
+            out[(long long)(g + i) * slot_pairs] = (S[i] + M) + P;
+        }
     }
 }
 
@@ -72,9 +83,14 @@ hipError_t tp_window_sums_launch(const double* G, double* Q, int nblk, size_t sl
                                  hipStream_t stream) {
     if (n_L < 1 || nblk < 1) return hipSuccess;
     const long long slot_pairs = (long long)(slot_doubles / 2);
-    const int runs = (nblk + TP_WINSUM_RUN - 1) / TP_WINSUM_RUN;
+    int groups = 1;                                         // the largest group count among the tables
+    for (int i = 0; i < n_L; ++i) {
+        const int Rr = L[i] < TP_WINSUM_RUN ? L[i] : TP_WINSUM_RUN;
+        const int npos = nblk - L[i] + 1;
+        if (Rr >= 1 && npos >= 1 && (npos + Rr - 1) / Rr > groups) groups = (npos + Rr - 1) / Rr;
+    }
     const int4 Ls = make_int4(L[0], n_L > 1 ? L[1] : 0, n_L > 2 ? L[2] : 0, n_L > 3 ? L[3] : 0);
-    hipLaunchKernelGGL(tp_window_sums_kernel, dim3((unsigned)((slot_pairs + 255) / 256), (unsigned)runs, (unsigned)n_L), dim3(256), 0,
+    hipLaunchKernelGGL(tp_window_sums_kernel, dim3((unsigned)((slot_pairs + 255) / 256), (unsigned)groups, (unsigned)n_L), dim3(256), 0,
                        stream, (const tp_d2*)G, (tp_d2*)Q, nblk, slot_pairs, Ls, n_L);
     return hipGetLastError();
 }

@@ -80,7 +80,7 @@ struct tp_launch_info_t { int grid, block, lds_bytes, ntile; };
 // Shared Gram prefixes of the register-tile path: aligned blocks of the staged chunk's rows (16; 32 with eight waves,
 // NT >= 13); 16 rows on the tiled path.
 #define TP_WINSUM_MAX_L 4           /* register-tile path: distinct whole-block counts per batch that get a table */
-#define TP_WINSUM_RUN 16            /* sliding sums restart every so many block positions */
+#define TP_WINSUM_RUN 16            /* block positions one thread of tp_window_sums_kernel serves (a group: posterior_fused.hip) */
 #define TP_PREFIX_BLOCK_ROWS(nt) ((nt) <= 12 ? 16 : 32)
 // doubles per table slot (one Gram of one block or block window: every upper-triangle tile, 4 registers x 64 lanes)
 inline size_t tp_fused_slot_doubles(int k) { const int nt = (k + 1 + 15) / 16; return (size_t)(nt * (nt + 1) / 2) * 256; }
@@ -90,7 +90,7 @@ inline size_t tp_fused_prefix_bytes(int k, long long panel_rows, int n_L, int* n
     if (nblk_out) *nblk_out = (int)nblk;
     return sizeof(double) * (size_t)nblk * (size_t)(1 + n_L) * tp_fused_slot_doubles(k);
 }
-// Q_L tables from the block Grams (posterior_fused.hip): elementwise sliding sums, restarted every TP_WINSUM_RUN positions
+// Q_L tables from the block Grams (posterior_fused.hip): elementwise, additions only, groups of TP_WINSUM_RUN positions
 hipError_t tp_window_sums_launch(const double* G, double* Q, int nblk, size_t slot_doubles, const int* L, int n_L,
                                  hipStream_t stream);
 

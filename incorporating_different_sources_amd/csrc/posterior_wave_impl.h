@@ -24,7 +24,7 @@
 
 namespace {
 
-template <int NT_>
+template <int NT_, bool LEAN_ = true>
 struct WCfg {
     static constexpr int NT = NT_;
     static constexpr int KP = 16 * NT;
@@ -36,7 +36,22 @@ struct WCfg {
     static constexpr int OFF_VEC = OFF_IDT + 256;                // [KP] column sums / Jeffreys t / y
     static constexpr int LDS_DOUBLES = OFF_VEC + KP;
     static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
+    // General (index) layout only, behind the fixed part: the panel rows of the pass in flight - and the daily pass's
+    // per-row risk-free adjustments - staged in LDS once per pass: [rows] doubles, then [rows] ints, rows = wave_idx_rows().
+    // Read from global memory inside the row loop they were a DEPENDENT load per k-step, and since s_waitcnt vmcnt counts
+    // in order, waiting for the youngest load (the index) drained the whole three-k-step pipeline of row loads every step
+    // (round 3: 30 % of the wave cycles of the index layout parked in s_waitcnt, 1.26 vs 1.04 ms at configs[1]).  LDS reads
+    // are counted by lgkmcnt and are fetched one k-step ahead.  Sized per batch (dynamic LDS); batches whose passes would
+    // not fit WAVE_LDS_LIMIT stay on the multi-wave kernel (wave_idx_fits).
+    static constexpr int OFF_SUB = LDS_DOUBLES;
 };
+constexpr int WAVE_LDS_LIMIT = 64 * 1024;
+// rows of the longest pass of a batch, rounded up to whole k-steps of 64 lanes' staging loads
+__host__ __device__ inline int wave_idx_rows(int n_r, int m, bool conj) {
+    const int r = (conj && m > n_r) ? m : n_r;
+    return (r + 63) & ~63;
+}
+__host__ __device__ inline int wave_idx_bytes(int n_r, int m, bool conj) { return wave_idx_rows(n_r, m, conj) * 12; }
 
 // row-major index of upper-triangle tile (I, J), I <= J - the numbering of the shared Gram tables
 constexpr int wtile(int NT, int I, int J) { return I * NT - I * (I - 1) / 2 + (J - I); }
@@ -113,10 +128,12 @@ struct WRows {
 //  beyond column k here, AFTER the first two k-steps' row loads have been issued - masking them at the call site made the
 //  wave wait for the shift row before it could ask for the first panel rows (two memory round trips in a row, and this
 //  wave has nothing else to run meanwhile)
+//  !LEAN: lds_rows[r] / lds_sub[r] hold the panel row and the subtrahend of row r of this pass (staged by wave_stage_rows)
 template <int NT, bool HF, bool LEAN>
 __device__ __forceinline__ void wave_gram(const WRows& src, const int* __restrict__ cols, int k, int lane,
                                           double (&shift)[NT], double (&w0v)[NT], bool ones, bool lazy_mask,
-                                          d4 (&acc)[WCfg<NT>::NTILES]) {
+                                          d4 (&acc)[WCfg<NT>::NTILES], const int* lds_rows = nullptr,
+                                          const double* lds_sub = nullptr) {
     constexpr int kI = NT - 1;
     const int fr = lane & 15, fq = lane >> 4;
     const int kc = k - 16 * kI;
@@ -133,17 +150,31 @@ __device__ __forceinline__ void wave_gram(const WRows& src, const int* __restric
         const int cl = c < k ? c : k - 1;
         coff[i] = (!LEAN && cols) ? (long long)cols[cl] : (long long)cl;
     }
+    // general layout: the pass's panel rows (and subtrahends) come from LDS; the values of the NEXT load are fetched right
+    // behind the current load's requests, a whole k-step of MFMAs ahead of their use
+    int row_pref = 0;
+    double sub_pref = 0.0;
+    auto prefetch = [&](int ks) __attribute__((always_inline)) {
+        int r = 4 * ks + fq;
+        r = r < src.count ? r : src.count - 1;
+        row_pref = lds_rows[r];
+        if (has_sub) sub_pref = lds_sub[r];
+    };
+    if constexpr (!LEAN) prefetch(0);
     auto load = [&](double (&v)[NT], double& sub, int ks) __attribute__((always_inline)) {
         int r = 4 * ks + fq;
         r = r < src.count ? r : src.count - 1;                      // rows past the end re-read the last row (masked below)
         long long row;
-        if (LEAN) row = src.first + r + (r >= src.count0 ? src.jump : 0);
-        else row = src.ridx ? (long long)src.ridx[r] : src.first + r;
+        if constexpr (LEAN) row = src.first + r + (r >= src.count0 ? src.jump : 0);
+        else row = (long long)row_pref;
         const double* p = src.base + row * src.ld;
 #pragma unroll
         for (int i = 0; i < NT; ++i) v[i] = p[coff[i]];
         sub = 0.0;
-        if (has_sub) sub = src.sub_row[r];
+        if constexpr (!LEAN) {
+            if (has_sub) sub = sub_pref;
+            prefetch(ks + 1);                                       // loads are issued for ks = 0, 1, 2, ... in this order
+        }
     };
     // MASK: the k-step may hold rows past the end (only the last three k-steps of a pass are built with it)
     auto step = [&](double (&v)[NT], double sub, int ks, auto maskc) __attribute__((always_inline)) {
@@ -216,6 +247,16 @@ __device__ __forceinline__ void wave_gram(const WRows& src, const int* __restric
     wave_settle<NT>(acc);
 }
 
+// General layout: panel row (and subtrahend) of every row of the pass into LDS, 64 rows per instruction.
+__device__ __forceinline__ void wave_stage_rows(const WRows& src, int lane, int* li, double* lsb) {
+    for (int i = lane; i < src.count; i += 64) {
+        li[i] = src.ridx ? src.ridx[i] : (int)(src.first + i);
+        if (src.sub_row) lsb[i] = src.sub_row[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // MODE 0: conjugate, 1: Jeffreys - the plain product paths, compiled without the read-back / custom right-hand side /
 // shift branches: every branch that merges two versions of the accumulators costs register copies or spills here (one
 // kernel with all of them decided at run time, MODE 2, needs 2.2 KB of scratch per lane against 44 bytes, and spill code
@@ -225,7 +266,7 @@ __device__ __forceinline__ void wave_gram(const WRows& src, const int* __restric
 template <int NT, bool LEAN, int MODE>
 __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* lds) {
     constexpr bool FULL = MODE == 2;
-    using C = WCfg<NT>;
+    using C = WCfg<NT, LEAN>;
     const int lane = threadIdx.x;
     const int fr = lane & 15, fq = lane >> 4;
     const int k = A.k;
@@ -244,6 +285,9 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
     (void)tid0;
 
     const int* cols = (!LEAN && A.col_idx) ? A.col_idx + w * k : nullptr;
+    // general layout: staging region of the pass in flight behind the fixed part of the LDS image
+    double* idx_sub_lds = LEAN ? nullptr : lds + C::OFF_SUB;
+    int* idx_rows_lds = LEAN ? nullptr : (int*)(lds + C::OFF_SUB + wave_idx_rows(A.n_r, A.m, A.strategy == 0));
     d4 acc[C::NTILES];
     static_for<0, C::NTILES>([&](auto tc) __attribute__((always_inline)) { acc[decltype(tc)::value] = d4{0.0, 0.0, 0.0, 0.0}; });
     // AGPR values from the first definition on: where two paths of the kernel meet, the accumulators must arrive as AGPR
@@ -354,7 +398,8 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
         const int hf_rows_all = hs.count;
         if (shifted && !hs.ridx) { hs.first += 1; hs.count -= 1; }
         else if (shifted) { hs.ridx += 1; hs.count -= 1; }
-        wave_gram<NT, true, LEAN>(hs, cols, k, lane, shift, w0v, shifted, shifted, acc);
+        if constexpr (!LEAN) wave_stage_rows(hs, lane, idx_rows_lds, idx_sub_lds);      // (WCfg::OFF_SUB)
+        wave_gram<NT, true, LEAN>(hs, cols, k, lane, shift, w0v, shifted, shifted, acc, idx_rows_lds, idx_sub_lds);
         hs.count = hf_rows_all;
         TP_MARK(2);
         // ---- phase C: rank-one term of the centring (one-pass form); q0, c, scaling (ref:333, 415-418).  ONE pass over
@@ -481,7 +526,9 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
                 }
             });
         };
-        wave_gram<NT, false, LEAN>(ds, cols, k, lane, none, none, false, false, acc);
+        // (every load of the intraday pass has completed: its staging region is free for the daily pass)
+        if constexpr (!LEAN) wave_stage_rows(ds, lane, idx_rows_lds, idx_sub_lds);
+        wave_gram<NT, false, LEAN>(ds, cols, k, lane, none, none, false, false, acc, idx_rows_lds, idx_sub_lds);
         TP_MARK(33);
         if (LEAN && shared) {
             // (issuing the first group in front of the edge rows' loop was measured and dropped: the loop's counted
@@ -766,19 +813,25 @@ __global__ void __launch_bounds__(64, wave_occupancy(NT)) posterior_wave_kernel(
     wave_window_body<NT, LEAN, MODE>(A, lds);
 }
 
+// LDS bytes of a launch: the fixed image, plus the staging region of the general layout (sized by the batch's passes)
+template <int NT, bool LEAN>
+inline int wave_lds_bytes(const tp_kargs_t& a) {
+    return WCfg<NT, LEAN>::LDS_BYTES + (LEAN ? 0 : wave_idx_bytes(a.n_r, a.m, a.strategy == 0));
+}
+
 template <int NT, bool LEAN, int MODE>
 hipError_t wave_launch_mode(const tp_kargs_t& a, int grid8, hipStream_t stream) {
-    using C = WCfg<NT>;
+    const int lds_bytes = wave_lds_bytes<NT, LEAN>(a);
+    if (lds_bytes > WAVE_LDS_LIMIT) return hipErrorInvalidValue;     // launch_one keeps such batches on the multi-wave kernel
     static std::atomic<unsigned long long> attr_done{0};      // one bit per device (tp_allow_dynamic_lds)
-    { hipError_t e = tp_allow_dynamic_lds(attr_done, posterior_wave_kernel<NT, LEAN, MODE>, C::LDS_BYTES); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL((posterior_wave_kernel<NT, LEAN, MODE>), dim3(grid8), dim3(64), C::LDS_BYTES, stream, a);
+    { hipError_t e = tp_allow_dynamic_lds(attr_done, posterior_wave_kernel<NT, LEAN, MODE>, WAVE_LDS_LIMIT); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL((posterior_wave_kernel<NT, LEAN, MODE>), dim3(grid8), dim3(64), lds_bytes, stream, a);
     return hipGetLastError();
 }
 
 template <int NT, bool LEAN>
 hipError_t wave_launch_variant(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info) {
-    using C = WCfg<NT>;
-    if (info) { info->grid = grid; info->block = 64; info->lds_bytes = C::LDS_BYTES; info->ntile = NT; }
+    if (info) { info->grid = grid; info->block = 64; info->lds_bytes = wave_lds_bytes<NT, LEAN>(a); info->ntile = NT; }
     const int grid8 = 8 * ((grid + 7) / 8);
     switch (wave_mode(a)) {
         case 0: return wave_launch_mode<NT, LEAN, 0>(a, grid8, stream);

@@ -57,7 +57,14 @@ struct tp_handle_s {
     int tiled_arena_mib = 0;        // TP_TILED_ARENA_MIB / "tiled_arena_mib": a sub-GiB arena (depth-first sub-batches)
     int phase_limit = 0;            // TP_PHASE_LIMIT (diagnostic builds only)
     std::vector<tp_batch_t> batches;   // live batches of this handle (destroyed with it if the caller forgot them)
+    // per-step kernel times inside a tp_region_begin / tp_region_end bracket: every timed launch of the region records
+    // its own event pair (no host wait in between), tp_region_end reads them all (tp_region_steps returns them)
+    std::vector<hipEvent_t> ring0, ring1;
+    int ring_used = 0;
+    bool in_region = false;
+    std::vector<double> step_ms;
 };
+#define TP_REGION_MAX_STEPS 512
 
 struct DevBuf {
     void* p = nullptr;
@@ -368,11 +375,16 @@ int launch(tp_batch_t b, const tp_kargs_t& a, int64_t count, bool timed) {
     tp_handle_t h = b->h;
     if (count <= 0) return TP_OK;
     if (count > 0x7fffffffLL) return fail(h, TP_ERR_INVALID, "too many windows in one launch");
+    // inside a region the launch is bracketed by its own pair of the ring (read by tp_region_end), outside by ev0 / ev1
+    hipEvent_t t0 = h->ev0, t1 = h->ev1;
+    const bool ring = timed && h->in_region && h->ring_used < (int)h->ring0.size();
+    if (ring) { t0 = h->ring0[(size_t)h->ring_used]; t1 = h->ring1[(size_t)h->ring_used]; }
+    auto timed_done = [&]() { if (ring) ++h->ring_used; else h->kernel_timed = true; };
     if (a.k <= tp_fused_max_assets()) {
-        if (timed) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+        if (timed) HIP_TRY(h, hipEventRecord(t0, h->stream));
         hipError_t e = tp_fused_launch(a, (int)count, h->stream, &h->last_launch, nullptr);
         if (e != hipSuccess) return fail(h, TP_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-        if (timed) { HIP_TRY(h, hipEventRecord(h->ev1, h->stream)); h->kernel_timed = true; }
+        if (timed) { HIP_TRY(h, hipEventRecord(t1, h->stream)); timed_done(); }
         return TP_OK;
     }
     // large-k path: sub-batches of in-flight windows through the tiled pipeline
@@ -380,7 +392,7 @@ int launch(tp_batch_t b, const tp_kargs_t& a, int64_t count, bool timed) {
     tp_tiled_ws_t ws;
     int rc = ensure_tiled_ws(b, &ws);
     if (rc != TP_OK) return rc;
-    if (timed) HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    if (timed) HIP_TRY(h, hipEventRecord(t0, h->stream));
     for (int64_t w0 = 0; w0 < count; w0 += b->tiled_capacity) {
         tp_kargs_t sub = a;
         sub.w_first = a.w_first + w0;
@@ -389,7 +401,7 @@ int launch(tp_batch_t b, const tp_kargs_t& a, int64_t count, bool timed) {
         if (e != hipSuccess) return fail(h, TP_ERR_HIP, "tiled pipeline launch failed: %s", hipGetErrorString(e));
     }
     h->last_launch = tp_launch_info_t{(int)(count < b->tiled_capacity ? count : b->tiled_capacity), 256, 36864, ws.NS * 4};
-    if (timed) { HIP_TRY(h, hipEventRecord(h->ev1, h->stream)); h->kernel_timed = true; }
+    if (timed) { HIP_TRY(h, hipEventRecord(t1, h->stream)); timed_done(); }
     return TP_OK;
 }
 
@@ -443,6 +455,8 @@ int destroy_handle(tp_handle_t h, bool device_calls) {
         if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
         for (hipEvent_t e : {h->cp0, h->cp1, h->ev0, h->ev1, h->reg0, h->reg1})
             if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : h->ring0) (void)hipEventDestroy(e);
+        for (hipEvent_t e : h->ring1) (void)hipEventDestroy(e);
         if (h->stream) (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -991,6 +1005,18 @@ int tp_last_timing(tp_handle_t h, double* kernel_ms, double* h2d_ms, double* d2h
 int tp_region_begin(tp_handle_t h) {
     if (!h) return TP_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->ring0.empty()) {
+        for (int i = 0; i < TP_REGION_MAX_STEPS; ++i) {
+            hipEvent_t a = nullptr, b = nullptr;
+            HIP_TRY(h, hipEventCreate(&a));
+            h->ring0.push_back(a);
+            HIP_TRY(h, hipEventCreate(&b));
+            h->ring1.push_back(b);
+        }
+    }
+    h->ring_used = 0;
+    h->step_ms.clear();
+    h->in_region = true;
     HIP_TRY(h, hipEventRecord(h->reg0, h->stream));
     return TP_OK;
 }
@@ -998,12 +1024,28 @@ int tp_region_begin(tp_handle_t h) {
 int tp_region_end(tp_handle_t h, double* ms) {
     if (!h) return TP_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
+    h->in_region = false;
     HIP_TRY(h, hipEventRecord(h->reg1, h->stream));
     HIP_TRY(h, hipEventSynchronize(h->reg1));
     float f = 0;
     HIP_TRY(h, hipEventElapsedTime(&f, h->reg0, h->reg1));
     if (ms) *ms = f;
+    for (int i = 0; i < h->ring_used; ++i) {
+        float s = 0;
+        HIP_TRY(h, hipEventElapsedTime(&s, h->ring0[(size_t)i], h->ring1[(size_t)i]));
+        h->step_ms.push_back((double)s);
+    }
+    if (!h->step_ms.empty()) h->kernel_ms = h->step_ms.back();
     return harvest_kernel_time(h);
+}
+
+int tp_region_steps(tp_handle_t h, double* step_ms, int capacity, int* n_steps) {
+    if (!h || !n_steps || capacity < 0) return TP_ERR_INVALID;
+    const int n = (int)h->step_ms.size();
+    *n_steps = n;
+    if (step_ms)
+        for (int i = 0; i < n && i < capacity; ++i) step_ms[i] = h->step_ms[(size_t)i];
+    return TP_OK;
 }
 
 int tp_last_launch(tp_handle_t h, int* grid, int* block, int* lds_bytes, int* ntile) {
