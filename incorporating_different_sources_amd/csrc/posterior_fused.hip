@@ -11,13 +11,13 @@ TP_DECL(9) TP_DECL(10) TP_DECL(11) TP_DECL(12) TP_DECL(13) TP_DECL(14) TP_DECL(1
 
 int tp_fused_max_assets(void) { return 16 * TP_MAX_NT - 1; }
 
-bool tp_use_wave_kernel(int nt, int choice) {
-    if (choice >= 0) return choice != 0;
-    // measured on MI355X (tools/sweep_k.py, both kernels in one run, gpurun_out/r03f/sweep.log and the round's later runs):
-    // one wave per window wins at every tile count it is built for: +10 % (k = 8) .. +55 % (k = 55), +24 % at k = 100,
-    // +22..31 % at 8 tiles (k = 112..127: four of the 36 tiles live in VGPRs), +15 % .. -2 % at 9 tiles (k = 128..143).
-    // Ten tiles per side (440 accumulator registers) no longer fit the register file next to the row pipeline.
-    return nt >= 1 && nt <= 9;
+int tp_pick_wave_kernel(int nt, int choice) {
+    if (choice >= 0) return choice;
+    // measured on MI355X (tools/sweep_k.py, the kernels in one run): one wave per window wins at every tile count it is
+    // built for: +10 % (k = 8) .. +55 % (k = 55), +24 % at k = 100, +22..31 % at 8 tiles, +15 % .. -2 % at 9 tiles (round 2).
+    // Ten tiles per side (440 accumulator registers) no longer fit one wave's register file next to the row pipeline:
+    // two waves per window up to 12 tiles per side, four up to 15 (posterior_wave2_impl.h, round 3).
+    return nt <= 9 ? 1 : 2;
 }
 
 hipError_t tp_fused_launch(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info,

@@ -1268,13 +1268,6 @@ hipError_t launch_variant(const tp_kargs_t& a, int grid, hipStream_t stream, tp_
     return hipGetLastError();
 }
 
-// LDS bytes of the one-wave kernel in the general layout (mirrors WCfg / wave_lds_bytes of posterior_wave_impl.h)
-inline int tp_wave_general_lds_bytes(int nt, const tp_kargs_t& a) {
-    const int fixed = 8 * (nt * 16 * 17 + 256 + 256 + 16 * nt);
-    const int rows = ((((a.strategy == 0 && a.m > a.n_r) ? a.m : a.n_r) + 63) & ~63);
-    return fixed + 12 * rows;
-}
-
 // launcher of the one-wave-per-window kernel of a tile count (posterior_wave_nt.hip), or nullptr
 typedef hipError_t (*tp_wave_launch_fn)(const tp_kargs_t&, int, hipStream_t, tp_launch_info_t*, bool lean);
 
@@ -1284,10 +1277,14 @@ hipError_t launch_one(const tp_kargs_t& a, int grid, hipStream_t stream, tp_laun
     static_assert(C::CH == TP_PREFIX_BLOCK_ROWS(NT), "posterior_kernels.h: block rows of the shared Gram prefixes");
     if (wave_mode(a) == 2) wave = nullptr;         // read-backs, custom right-hand sides, shifts: the multi-wave kernel
     if (!tp_layout_is_lean(a)) {
-        // general layout: the one-wave kernel stages a pass's row indices in LDS (posterior_wave_impl.h, WCfg::OFF_SUB);
-        // passes too long for that (about 3,500 rows) stay on the multi-wave kernel
-        if (wave && tp_wave_general_lds_bytes(NT, a) > 64 * 1024) wave = nullptr;
-        return wave ? wave(a, grid, stream, info, false) : launch_variant<NT, NW, false>(a, grid, stream, info);
+        // general layout: the one- / two-wave kernels stage a pass's row indices in LDS (posterior_wave_impl.h,
+        // WCfg::OFF_SUB); a batch whose passes are too long for that is answered with hipErrorNotSupported before anything
+        // is launched and stays on the multi-wave kernel
+        if (wave) {
+            const hipError_t e = wave(a, grid, stream, info, false);
+            if (e != hipErrorNotSupported) return e;
+        }
+        return launch_variant<NT, NW, false>(a, grid, stream, info);
     }
     if (a.winsum != nullptr) {
         // the shared sums first, on the same stream: part of every run, nothing is kept between runs
@@ -1302,7 +1299,11 @@ hipError_t launch_one(const tp_kargs_t& a, int grid, hipStream_t stream, tp_laun
         e = tp_window_sums_launch(a.prefix, (double*)a.winsum, a.prefix_nblk, (size_t)C::NTILES * 256, a.winsum_L, n_L, stream);
         if (e != hipSuccess) return e;
     }
-    return wave ? wave(a, grid, stream, info, true) : launch_variant<NT, NW, true>(a, grid, stream, info);
+    if (wave) {
+        const hipError_t e = wave(a, grid, stream, info, true);
+        if (e != hipErrorNotSupported) return e;
+    }
+    return launch_variant<NT, NW, true>(a, grid, stream, info);
 }
 
 template <int NT, int NW>

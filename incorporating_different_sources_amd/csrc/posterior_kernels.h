@@ -94,9 +94,10 @@ inline size_t tp_fused_prefix_bytes(int k, long long panel_rows, int n_L, int* n
 hipError_t tp_window_sums_launch(const double* G, double* Q, int nblk, size_t slot_doubles, const int* L, int n_L,
                                  hipStream_t stream);
 
-// which register-tile kernel runs a tile count: the one-wave-per-window kernel (posterior_wave_impl.h) or the
-// multi-wave kernel (posterior_fused_impl.h); `choice` = tp_kopts_t::wave_kernel overrides it (A/B measurements)
-bool tp_use_wave_kernel(int nt, int choice);
+// which register-tile kernel runs a tile count: 0 = the multi-wave kernel (posterior_fused_impl.h), 1 = one wave per
+// window (posterior_wave_impl.h), 2 = two / four waves per window (posterior_wave2_impl.h); `choice` =
+// tp_kopts_t::wave_kernel >= 0 overrides the automatic pick (A/B measurements)
+int tp_pick_wave_kernel(int nt, int choice);
 // 0 / 1: a plain conjugate / Jeffreys batch (weights, statuses, aux only) - what the one-wave kernel is built for;
 // 2: a batch with a matrix read-back, a custom right-hand side, tp_batch_keep_rhs, a shift or a non-default centring
 inline int wave_mode(const tp_kargs_t& a) {

@@ -174,6 +174,8 @@ __device__ __forceinline__ void wave_gram(const WRows& src, const int* __restric
         if constexpr (!LEAN) {
             if (has_sub) sub = sub_pref;
             prefetch(ks + 1);                                       // loads are issued for ks = 0, 1, 2, ... in this order
+        } else {
+            if (has_sub) sub = src.sub_row[r];                       // contiguous rows with a risk-free adjustment (rare)
         }
     };
     // MASK: the k-step may hold rows past the end (only the last three k-steps of a pass are built with it)
@@ -822,7 +824,7 @@ inline int wave_lds_bytes(const tp_kargs_t& a) {
 template <int NT, bool LEAN, int MODE>
 hipError_t wave_launch_mode(const tp_kargs_t& a, int grid8, hipStream_t stream) {
     const int lds_bytes = wave_lds_bytes<NT, LEAN>(a);
-    if (lds_bytes > WAVE_LDS_LIMIT) return hipErrorInvalidValue;     // launch_one keeps such batches on the multi-wave kernel
+    if (lds_bytes > WAVE_LDS_LIMIT) return hipErrorNotSupported;     // nothing launched: launch_one falls back to the multi-wave kernel
     static std::atomic<unsigned long long> attr_done{0};      // one bit per device (tp_allow_dynamic_lds)
     { hipError_t e = tp_allow_dynamic_lds(attr_done, posterior_wave_kernel<NT, LEAN, MODE>, WAVE_LDS_LIMIT); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL((posterior_wave_kernel<NT, LEAN, MODE>), dim3(grid8), dim3(64), lds_bytes, stream, a);
@@ -836,7 +838,7 @@ hipError_t wave_launch_variant(const tp_kargs_t& a, int grid, hipStream_t stream
     switch (wave_mode(a)) {
         case 0: return wave_launch_mode<NT, LEAN, 0>(a, grid8, stream);
         case 1: return wave_launch_mode<NT, LEAN, 1>(a, grid8, stream);
-        default: return hipErrorInvalidValue;        // launch_one keeps such batches on the multi-wave kernel
+        default: return hipErrorNotSupported;        // launch_one keeps such batches on the multi-wave kernel
     }
 }
 

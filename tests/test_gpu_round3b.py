@@ -180,3 +180,100 @@ def test_options_are_per_handle_and_the_environment_is_read_once(native, monkeyp
             dev2.close()
     finally:
         dev.close()
+
+
+# ---- the two- / four-wave-per-window kernel (csrc/posterior_wave2_impl.h): 10..15 tiles per side, 144 <= k <= 239 ------
+def _kw(inp, strat):
+    kw = dict(panel=inp["panel"], start=inp["start"], n_r=inp["n_r"])
+    if strat == "conjugate":
+        kw.update(hf_panel=inp["hf_panel"], hf_start=inp["hf_start"], m=inp["m"], w0=inp["w0"], n0=inp["n0"])
+    return kw
+
+
+@pytest.mark.parametrize("strat", ["conjugate", "jeffreys"])
+def test_every_universe_size_of_the_two_wave_kernel(native, strat):
+    """EVERY k = 144 .. 239 (six tile counts; two waves per window up to 12 tiles per side, four above; every position
+    of the border column inside its tile, the two-pass sizes k + 1 = 0 mod 16) on the kernel the library now picks for
+    these sizes: against the oracle at the flat 1e-10 and against the multi-wave kernel it replaces (same arithmetic per
+    element up to the order of the partial sums of the back substitution: 1e-12).  Also a few sizes of the one-wave
+    kernel's range (7 .. 9 tiles per side), where the two-wave kernel is built for A/B runs."""
+    dev = native.default_device()
+    worst = 0.0
+    try:
+        for k in list(range(144, 240)) + [96, 100, 111, 112, 127, 128, 143]:
+            N = max(2 * k + 10, 40) if strat == "jeffreys" else max(k + 30, 40)
+            inp = synthetic.make_kernel_inputs(k, N, 7, seed=41000 + k, hf_days=2 if k > 150 else 1)
+            kw = _kw(inp, strat)
+            ref, rstat, _ = oracle.posterior_batch_c(strat, k, N, 5.0, **kw)
+            dev.set_option("wave_kernel", 0)
+            w_multi, s_multi, a_multi = native.posterior_batch(strat, k, N, 5.0, **kw)
+            assert dev.last_launch()["block"] >= 256
+            dev.set_option("wave_kernel", 2)
+            w_two, s_two, a_two = native.posterior_batch(strat, k, N, 5.0, **kw)
+            assert dev.last_launch()["block"] == (128 if k <= 191 else 256), (k, dev.last_launch())
+            assert (s_two == rstat).all() and (s_multi == rstat).all(), (k, s_two, rstat)
+            np.testing.assert_allclose(w_two, ref, rtol=0, atol=1e-10, err_msg=f"k={k}")
+            np.testing.assert_allclose(w_two, w_multi, rtol=0, atol=1e-12, err_msg=f"k={k}")
+            np.testing.assert_allclose(a_two[:, :6], a_multi[:, :6], rtol=1e-12, atol=1e-300, err_msg=f"k={k}")
+            worst = max(worst, float(np.abs(w_two - ref).max()))
+            if k >= 144:
+                dev.set_option("wave_kernel", -1)                      # the automatic pick IS the two-wave kernel there
+                w_auto, _, _ = native.posterior_batch(strat, k, N, 5.0, **kw)
+                assert np.array_equal(w_auto, w_two) and dev.last_launch()["block"] in (128, 256)
+    finally:
+        dev.set_option("wave_kernel", -1)
+    assert worst < 1e-10
+
+
+@pytest.mark.parametrize("k,N", [(150, 200), (191, 260), (200, 250), (239, 300)])
+def test_two_wave_kernel_layouts_shared_sums_and_singular_windows(native, k, N):
+    """The two-wave kernel in every layout: rolling windows with shared Gram sums (400 windows), the same without
+    sharing (bitwise the index layout's results with identity indices), ragged index-layout windows with gathered
+    columns and a per-row risk-free adjustment against the oracle; a rank-deficient Jeffreys batch is flagged."""
+    rng = np.random.default_rng(k)
+    W = 400
+    inp = synthetic.make_kernel_inputs(k, N, W, seed=4300 + k, hf_days=3)
+    n_r, m = inp["n_r"], inp["m"]
+    kw = _kw(inp, "conjugate")
+    dev = native.default_device()
+    b = native.Batch(dev, "conjugate", k, N, n_r, 5.0, W, m)
+    try:
+        b.upload(**{key: val for key, val in kw.items() if key not in ("n_r", "m")})
+        assert b.shared_gram_blocks() > 0
+        b.run()
+        w_sh, s_sh, a_sh = b.download()
+        assert dev.last_launch()["block"] in (128, 256)
+    finally:
+        b.close()
+    w_no, s_no, a_no = native.posterior_batch("conjugate", k, N, 5.0, flags=native.FLAG_NO_SHARED_GRAM, **kw)
+    ikw = dict(panel=inp["panel"], n_r=n_r, row_idx=(inp["start"][:, None] + np.arange(n_r)[None, :]).astype(np.int32),
+               col_idx=np.tile(np.arange(k, dtype=np.int32), (W, 1)), rf_adj=np.zeros((W, n_r)), hf_panel=inp["hf_panel"], m=m,
+               hf_row_idx=(inp["hf_start"][:, None] + np.arange(m)[None, :]).astype(np.int32), w0=inp["w0"], n0=inp["n0"])
+    w_ix, s_ix, a_ix = native.posterior_batch("conjugate", k, N, 5.0, **ikw)
+    assert (s_sh == 0).all() and (s_no == 0).all() and (s_ix == 0).all()
+    assert np.array_equal(w_no, w_ix)                                   # same rows, same order, same arithmetic
+    np.testing.assert_allclose(w_sh, w_no, rtol=0, atol=1e-12)
+    sample = np.unique(rng.integers(0, W, 6))
+    ref, rstat, raux = oracle.posterior_batch_c("conjugate", k, N, 5.0, **{key: (val[sample] if key in ("start", "hf_start", "w0", "n0") else val)
+                                                                            for key, val in kw.items()})
+    np.testing.assert_allclose(w_sh[sample], ref, **WTOL)
+    np.testing.assert_allclose(a_sh[sample, :6], raux[:, :6], rtol=1e-11, atol=1e-14)
+    # ragged general layout
+    Wg = 10
+    col_idx = np.stack([np.sort(rng.choice(k, k - 9, replace=False)) for _ in range(Wg)]).astype(np.int32)
+    kg = k - 9
+    row_idx = np.stack([inp["start"][w] + np.sort(rng.choice(n_r, n_r, replace=False)) for w in range(Wg)]).astype(np.int32)
+    n_rows = rng.integers(n_r - 9, n_r + 1, size=Wg).astype(np.int32)
+    rf_adj = rng.normal(0, 1e-4, size=(Wg, n_r))
+    w0 = np.abs(rng.normal(size=(Wg, kg))); w0 /= w0.sum(axis=1, keepdims=True)
+    gkw = dict(panel=inp["panel"], start=None, row_idx=row_idx, n_rows=n_rows, col_idx=col_idx, rf_adj=rf_adj, n_r=n_r,
+               hf_panel=inp["hf_panel"], hf_start=inp["hf_start"][:Wg], m=m, hf_count=rng.integers(m - 20, m + 1, Wg).astype(np.int32),
+               w0=w0, n0=inp["n0"][:Wg])
+    refg, rstatg, _ = oracle.posterior_batch_c("conjugate", kg, N, 5.0, **gkw)
+    wg, sg, _ = native.posterior_batch("conjugate", kg, N, 5.0, **gkw)
+    assert (sg == rstatg).all()
+    np.testing.assert_allclose(wg, refg, **WTOL)
+    # singular: more assets than rows
+    sing = synthetic.make_kernel_inputs(k, 60, 5, seed=1)
+    _, s, _ = native.posterior_batch("jeffreys", k, 60, 5.0, panel=sing["panel"], start=sing["start"], n_r=sing["n_r"])
+    assert (s != 0).all()
