@@ -108,7 +108,8 @@ __device__ __forceinline__ void w2_settle(d4 (&acc)[N]) {
 template <int NT, int NWV, int WV, bool HF, bool LEAN>
 __device__ __forceinline__ void w2_gram(const WRows& src, const int* __restrict__ cols, int k, int lane,
                                         double (&shift)[NT], double (&w0v)[NT], bool ones, bool lazy_mask,
-                                        d4 (&acc)[w2_count<NT, NWV>(WV)], const int* lds_rows, const double* lds_sub) {
+                                        d4 (&acc)[w2_count<NT, NWV>(WV)], const int* lds_rows, const double* lds_sub,
+                                        double (&csum)[NT], double& usum) {
     constexpr int NS = w2_count<NT, NWV>(WV);
     constexpr int kI = NT - 1;
     const int fr = lane & 15, fq = lane >> 4;
@@ -171,6 +172,14 @@ __device__ __forceinline__ void w2_gram(const WRows& src, const int* __restrict_
 #pragma unroll
             for (int i = 0; i < NT; ++i) z = fma(v[i], w0v[i], z);
             z = rowgroup_sum16(z);
+            if (!ones) {
+                // k + 1 = 0 (mod 16): no spare column for the ones of the one-pass centring - the column sums of the
+                // shifted rows (and the sum of u) are kept by vector adds instead: NT + 1 per k-step next to the MFMAs.
+                // Round 2 ran a separate pass for the column MEANS at these sizes (13.8 % of a window's time at k = 191).
+#pragma unroll
+                for (int i = 0; i < NT; ++i) csum[i] += v[i];
+                usum += z;
+            }
             if (fr == kc) v[kI] = z;                                 // u_r = (y_r - shift).w0
         }
         static_for<0, NT>([&](auto Ic) __attribute__((always_inline)) {
@@ -269,6 +278,7 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
     double n0 = 0.0, cc = 0.0, q0 = 0.0;
     constexpr bool conj = MODE == 0;
 
+    TP_MARK(0);
     if constexpr (conj) {
         n0 = A.n0[w];
         WRows hs;
@@ -278,9 +288,10 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
         hs.sub_row = nullptr;
         hs.count = A.hf_count ? A.hf_count[w] : A.m;
         hs.count0 = 0x7fffffff; hs.jump = 0;
-        // ---- phase A: shift row (one-pass centred scatter) or column means (k+1 = 0 mod 16); every wave for itself
-        const bool shifted = kc < 15;
-        double shift[NT], w0v[NT];
+        // ---- phase A: the shift row of the one-pass centred scatter = the window's first intraday row; every wave for itself
+        const bool ones = kc < 15;        // a spare column k+1 carries ones; otherwise the sums are kept by vector adds (w2_gram)
+        double shift[NT], w0v[NT], csum[NT];
+        double usum = 0.0;
         {
             const long long row0 = hs.ridx ? (long long)hs.ridx[0] : hs.first;
             const double* p0 = hs.base + row0 * (long long)hs.ld;
@@ -290,43 +301,18 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
                 const int cl = c < k ? c : k - 1;
                 shift[i] = p0[cols ? cols[cl] : cl];
                 w0v[i] = A.w0[w * k + cl];
+                csum[i] = 0.0;
             }
         }
-        if (!shifted) {
-#pragma unroll
-            for (int i = 0; i < NT; ++i) w0v[i] = (16 * i + fr < k) ? w0v[i] : 0.0;
-            double cs[NT];
-#pragma unroll
-            for (int i = 0; i < NT; ++i) cs[i] = 0.0;
-            const int nks = (hs.count + 3) >> 2;
-            for (int ks = 0; ks < nks; ++ks) {
-                const int r = 4 * ks + fq;
-                const int rc = r < hs.count ? r : hs.count - 1;
-                const long long row = hs.ridx ? (long long)hs.ridx[rc] : hs.first + rc;
-                const double* p = hs.base + row * (long long)hs.ld;
-#pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    const int c = 16 * i + fr;
-                    const int cl = c < k ? c : k - 1;
-                    const double x = p[cols ? cols[cl] : cl];
-                    cs[i] += (r < hs.count) ? x : 0.0;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                double s = cs[i];
-                s += __shfl_xor(s, 16, 64);
-                s += __shfl_xor(s, 32, 64);
-                shift[i] = (16 * i + fr < k) ? s / (double)hs.count : 0.0;
-            }
-        }
-        // ---- phase B: Gram of the shifted / centred intraday rows (row 0, shifted by itself, is exactly zero: skipped)
+        TP_MARK(1);
+        // ---- phase B: Gram of the shifted intraday rows (row 0, shifted by itself, is exactly zero: skipped)
         const int hf_rows_all = hs.count;
-        if (shifted && !hs.ridx) { hs.first += 1; hs.count -= 1; }
-        else if (shifted) { hs.ridx += 1; hs.count -= 1; }
+        if (!hs.ridx) { hs.first += 1; hs.count -= 1; }
+        else { hs.ridx += 1; hs.count -= 1; }
         if constexpr (!LEAN) w2_stage_rows(hs, tid, C::NTHREADS, idx_rows_lds, idx_sub_lds);
-        w2_gram<NT, NWV, WV, true, LEAN>(hs, cols, k, lane, shift, w0v, shifted, shifted, acc, idx_rows_lds, idx_sub_lds);
+        w2_gram<NT, NWV, WV, true, LEAN>(hs, cols, k, lane, shift, w0v, ones, true, acc, idx_rows_lds, idx_sub_lds, csum, usum);
         hs.count = hf_rows_all;
+        TP_MARK(2);
         // ---- phase C: rank-one term of the centring, q0, c, scaling (ref:333, 415-418)
         const double invm = 1.0 / (double)hs.count;
         if constexpr (WV == OWN_KI) {
@@ -341,7 +327,7 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
                 const int rr = kc >> 2;
                 cz0 = rr == 0 ? x0 : rr == 1 ? x1 : rr == 2 ? x2 : x3;
             }
-            if (shifted) {
+            if (ones) {
                 // column k+1 holds t_i = sum_r (y_r - s)_i for the asset columns and sum_r u_r in row k
                 static_for<0, NT>([&](auto Ic) __attribute__((always_inline)) {
                     constexpr int I = decltype(Ic)::value;
@@ -352,20 +338,31 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
                             lds[C::OFF_VEC + 16 * I + fq + 4 * r] = (I < kI || fq + 4 * r <= kc) ? acc[t][r] : 0.0;
                     }
                 });
+            } else {
+                // the same vector from the vector-add sums: the four row groups of a lane column meet by shuffles
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    double sc_ = csum[i];
+                    sc_ += __shfl_xor(sc_, 16, 64);
+                    sc_ += __shfl_xor(sc_, 32, 64);
+                    if (fq == 0) lds[C::OFF_VEC + 16 * i + fr] = (16 * i + fr < k) ? sc_ : 0.0;
+                }
+                double su = usum;
+                su += __shfl_xor(su, 16, 64);
+                su += __shfl_xor(su, 32, 64);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) lds[C::OFF_VEC + k] = su;            // row k: sum_r u_r (after the zero the loop above put there)
             }
             if (lane == 0) lds[C::OFF_SCAL + 0] = cz0;
         }
         __syncthreads();
         double tj[NT];
-#pragma unroll
-        for (int J = 0; J < NT; ++J) tj[J] = 0.0;
         double cz = lds[C::OFF_SCAL + 0];
-        if (shifted) {
+        const double tk = lds[C::OFF_VEC + k];
 #pragma unroll
-            for (int J = 0; J < NT; ++J) tj[J] = lds[C::OFF_VEC + 16 * J + fr];      // zero beyond column k
-            const double tk = lds[C::OFF_VEC + k];
-            cz = fma(-(tk * invm), tk, cz);
-        }
+        for (int J = 0; J < NT; ++J) tj[J] = lds[C::OFF_VEC + 16 * J + fr];          // column k: sum u; zero beyond
+        cz = fma(-(tk * invm), tk, cz);
         const double mm = (double)hs.count;
         const double sc = n0 * (mm / (mm - 1.0));
         q0 = sc * cz;
@@ -375,20 +372,16 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
         static_for<0, NT>([&](auto Ic) __attribute__((always_inline)) {
             constexpr int I = decltype(Ic)::value;
             if constexpr (w2_owns_from<NT, NWV>(WV, I)) {
-                double ti[4] = {0.0, 0.0, 0.0, 0.0};
-                if (shifted) {
+                double ti[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ti[r] = -(lds[C::OFF_VEC + 16 * I + fq + 4 * r] * invm);
-                }
+                for (int r = 0; r < 4; ++r) ti[r] = -(lds[C::OFF_VEC + 16 * I + fq + 4 * r] * invm);
                 static_for<I, NT>([&](auto Jc) __attribute__((always_inline)) {
                     constexpr int J = decltype(Jc)::value;
                     if constexpr (w2_owner<NT, NWV>(J) == WV) {
                         constexpr int t = w2_slot<NT, NWV>(I, J);
                         d4 x = acc[t];
-                        if (shifted) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) x[r] = fma(ti[r], tj[J], x[r]);
-                        }
+                        for (int r = 0; r < 4; ++r) x[r] = fma(ti[r], tj[J], x[r]);
                         if constexpr (J < kI) {
                             x *= sc;
                         } else if constexpr (I < kI) {
@@ -405,6 +398,7 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
             }
         });
     }
+    TP_MARK(3);
     // ---- phase D: daily Gram (ref:180) + t in the border column (ref:222)
     {
         WRows ds;
@@ -433,7 +427,10 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
             }
         }
         if constexpr (!LEAN) w2_stage_rows(ds, tid, C::NTHREADS, idx_rows_lds, idx_sub_lds);
-        w2_gram<NT, NWV, WV, false, LEAN>(ds, cols, k, lane, none, none, false, false, acc, idx_rows_lds, idx_sub_lds);
+        TP_MARK(32);
+        double nosum = 0.0;
+        w2_gram<NT, NWV, WV, false, LEAN>(ds, cols, k, lane, none, none, false, false, acc, idx_rows_lds, idx_sub_lds, none, nosum);
+        TP_MARK(33);
         if (LEAN && shared) {
             // this wave's tiles of the table slot Q_L[b0]: [tile][2][64 lanes][2] doubles (the table numbers the tiles
             // row-major over the whole triangle), two 16-byte reads per tile, six tiles' reads ahead of the additions
@@ -483,6 +480,7 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
             });
         }
     }
+    TP_MARK(34);
     // rows >= k of the bordered matrix are never pivots: clear them (they hold 1'X, n_r, ...)
     if constexpr (WV == OWN_KI) {
         constexpr int t = w2_slot<NT, NWV>(kI, kI);
@@ -536,6 +534,7 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
         });
     }
 
+    TP_MARK(4);
     // ---- phase F: blocked upper Cholesky S1 = R'R with the border column riding along (y = R^-T b)
     double badacc = 0.0;
     static_for<0, NT>([&](auto jc) __attribute__((always_inline)) {
@@ -639,6 +638,7 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
         }
     });
 
+    TP_MARK(5);
     // ---- phase G: y, q1 = y'y (ref:574), back substitution R w = y along block rows
     {
         const bool notpd_w = __any((badacc != badacc) ? 1 : 0) != 0;
@@ -704,6 +704,7 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
         }
     });
 
+    TP_MARK(6);
     // ---- phase H: weights, status, aux (ref:572-575, 836 / 849) - wave 0 writes them
     __syncthreads();          // (NTB == 0 cannot happen: k >= 16 (NT-1) >= 16; the flags and q1 were published by the barriers above)
     if constexpr (WV == 0) {
@@ -739,6 +740,7 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
             }
         }
     }
+    TP_MARK(7);
 }
 
 template <int NT, int NWV, bool LEAN, int MODE>

@@ -132,8 +132,8 @@ struct WRows {
 template <int NT, bool HF, bool LEAN>
 __device__ __forceinline__ void wave_gram(const WRows& src, const int* __restrict__ cols, int k, int lane,
                                           double (&shift)[NT], double (&w0v)[NT], bool ones, bool lazy_mask,
-                                          d4 (&acc)[WCfg<NT>::NTILES], const int* lds_rows = nullptr,
-                                          const double* lds_sub = nullptr) {
+                                          d4 (&acc)[WCfg<NT>::NTILES], const int* lds_rows, const double* lds_sub,
+                                          double (&csum)[NT], double& usum) {
     constexpr int kI = NT - 1;
     const int fr = lane & 15, fq = lane >> 4;
     const int kc = k - 16 * kI;
@@ -199,6 +199,14 @@ __device__ __forceinline__ void wave_gram(const WRows& src, const int* __restric
 #pragma unroll
             for (int i = 0; i < NT; ++i) z = fma(v[i], w0v[i], z);
             z = rowgroup_sum16(z);
+            if (!ones) {
+                // k + 1 = 0 (mod 16): no spare column for the ones of the one-pass centring - the column sums of the
+                // shifted rows (and the sum of u) are kept by vector adds instead: NT + 1 per k-step next to the MFMAs
+                // (round 2 ran a separate pass for the column MEANS at these sizes: a second dependent trip to memory)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) csum[i] += v[i];
+                usum += z;
+            }
             if (fr == kc) v[kI] = z;                                 // u_r = (y_r - shift).w0
         }
         static_for<0, NT>([&](auto Ic) __attribute__((always_inline)) {
@@ -348,9 +356,10 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
         hs.sub_row = nullptr;
         hs.count = A.hf_count ? A.hf_count[w] : A.m;
         hs.count0 = 0x7fffffff; hs.jump = 0;
-        // ---- phase A: shift row (one-pass centred scatter, see posterior_fused_impl.h) or column means (k+1 = 0 mod 16)
-        const bool shifted = kc < 15;
-        double shift[NT], w0v[NT];
+        // ---- phase A: the shift row of the one-pass centred scatter (see posterior_fused_impl.h) = the window's first row
+        const bool ones = kc < 15;        // a spare column k+1 carries ones; otherwise the sums are kept by vector adds (wave_gram)
+        double shift[NT], w0v[NT], csum[NT];
+        double usum = 0.0;
         {
             const long long row0 = hs.ridx ? (long long)hs.ridx[0] : hs.first;
             const double* p0 = hs.base + row0 * (long long)hs.ld;
@@ -360,48 +369,20 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
                 const int cl = c < k ? c : k - 1;
                 const double sv = p0[cols ? cols[cl] : cl];
                 const double wv = A.w0[w * k + cl];
-                shift[i] = sv;               // raw: zeroed beyond column k inside wave_gram (lazy_mask) or just below
+                shift[i] = sv;               // raw: zeroed beyond column k inside wave_gram (lazy_mask)
                 w0v[i] = wv;
-            }
-        }
-        if (!shifted) {
-#pragma unroll
-            for (int i = 0; i < NT; ++i) w0v[i] = (16 * i + fr < k) ? w0v[i] : 0.0;
-            // two-pass form: column means first (every lane group sums its rows, the four groups meet by shuffles)
-            double cs[NT];
-#pragma unroll
-            for (int i = 0; i < NT; ++i) cs[i] = 0.0;
-            const int nks = (hs.count + 3) >> 2;
-            for (int ks = 0; ks < nks; ++ks) {
-                const int r = 4 * ks + fq;
-                const int rc = r < hs.count ? r : hs.count - 1;
-                const long long row = hs.ridx ? (long long)hs.ridx[rc] : hs.first + rc;
-                const double* p = hs.base + row * (long long)hs.ld;
-#pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    const int c = 16 * i + fr;
-                    const int cl = c < k ? c : k - 1;
-                    const double x = p[cols ? cols[cl] : cl];
-                    cs[i] += (r < hs.count) ? x : 0.0;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                double s = cs[i];
-                s += __shfl_xor(s, 16, 64);
-                s += __shfl_xor(s, 32, 64);
-                shift[i] = (16 * i + fr < k) ? s / (double)hs.count : 0.0;
+                csum[i] = 0.0;
             }
         }
         TP_MARK(1);
-        // ---- phase B: Gram of the shifted / centred intraday rows
+        // ---- phase B: Gram of the shifted intraday rows
         // the shift row is the window's FIRST row: shifted it is exactly zero and adds nothing to any sum, so the pass
         // starts at row 1 (77 intraday rows: 19 k-steps instead of 20); the means of phase C still divide by all rows
         const int hf_rows_all = hs.count;
-        if (shifted && !hs.ridx) { hs.first += 1; hs.count -= 1; }
-        else if (shifted) { hs.ridx += 1; hs.count -= 1; }
+        if (!hs.ridx) { hs.first += 1; hs.count -= 1; }
+        else { hs.ridx += 1; hs.count -= 1; }
         if constexpr (!LEAN) wave_stage_rows(hs, lane, idx_rows_lds, idx_sub_lds);      // (WCfg::OFF_SUB)
-        wave_gram<NT, true, LEAN>(hs, cols, k, lane, shift, w0v, shifted, shifted, acc, idx_rows_lds, idx_sub_lds);
+        wave_gram<NT, true, LEAN>(hs, cols, k, lane, shift, w0v, ones, true, acc, idx_rows_lds, idx_sub_lds, csum, usum);
         hs.count = hf_rows_all;
         TP_MARK(2);
         // ---- phase C: rank-one term of the centring (one-pass form); q0, c, scaling (ref:333, 415-418).  ONE pass over
@@ -409,10 +390,8 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
         // way - all 224 registers at once would spill, and a spill reload costs this lone wave a full memory round trip.
         const double invm = 1.0 / (double)hs.count;
         double tj[NT];
-#pragma unroll
-        for (int J = 0; J < NT; ++J) tj[J] = 0.0;
         double cz = corner();                                       // z'z = w0'C w0 (before the rank-one term)
-        if (shifted) {
+        if (ones) {
             // column k+1 holds t_i = sum_r (y_r - s)_i for the asset columns and sum_r u_r in row k
             static_for<0, NT>([&](auto Ic) __attribute__((always_inline)) {
                 constexpr int I = decltype(Ic)::value;
@@ -423,10 +402,27 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
                         lds[C::OFF_VEC + 16 * I + fq + 4 * r] = (I < kI || fq + 4 * r <= kc) ? acc[t][r] : 0.0;
                 }
             });
+        } else {
+            // the same vector from the vector-add sums: the four row groups of a lane column meet by shuffles
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                double sc_ = csum[i];
+                sc_ += __shfl_xor(sc_, 16, 64);
+                sc_ += __shfl_xor(sc_, 32, 64);
+                if (fq == 0) lds[C::OFF_VEC + 16 * i + fr] = (16 * i + fr < k) ? sc_ : 0.0;
+            }
+            double su = usum;
+            su += __shfl_xor(su, 16, 64);
+            su += __shfl_xor(su, 32, 64);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if (lane == 0) lds[C::OFF_VEC + k] = su;                // row k: sum_r u_r (over the zero the loop above put there)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int J = 0; J < NT; ++J) tj[J] = lds[C::OFF_VEC + 16 * J + fr];      // zero beyond column k
+        for (int J = 0; J < NT; ++J) tj[J] = lds[C::OFF_VEC + 16 * J + fr];          // column k: sum u; zero beyond
+        {
             const double tk = lds[C::OFF_VEC + k];
             cz = fma(-(tk * invm), tk, cz);
         }
@@ -439,19 +435,15 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
         const double fcol = colv ? sc : ((fr == kc) ? cc * sc : 0.0);
         static_for<0, NT>([&](auto Ic) __attribute__((always_inline)) {
             constexpr int I = decltype(Ic)::value;
-            double ti[4] = {0.0, 0.0, 0.0, 0.0};
-            if (shifted) {
+            double ti[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ti[r] = -(lds[C::OFF_VEC + 16 * I + fq + 4 * r] * invm);
-            }
+            for (int r = 0; r < 4; ++r) ti[r] = -(lds[C::OFF_VEC + 16 * I + fq + 4 * r] * invm);
             static_for<I, NT>([&](auto Jc) __attribute__((always_inline)) {
                 constexpr int J = decltype(Jc)::value;
                 constexpr int t = wtile(NT, I, J);
                 d4 x = acc[t];
-                if (shifted) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) x[r] = fma(ti[r], tj[J], x[r]);
-                }
+                for (int r = 0; r < 4; ++r) x[r] = fma(ti[r], tj[J], x[r]);
                 if constexpr (J < kI) {
                     x *= sc;
                 } else if constexpr (I < kI) {
@@ -530,7 +522,8 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
         };
         // (every load of the intraday pass has completed: its staging region is free for the daily pass)
         if constexpr (!LEAN) wave_stage_rows(ds, lane, idx_rows_lds, idx_sub_lds);
-        wave_gram<NT, false, LEAN>(ds, cols, k, lane, none, none, false, false, acc, idx_rows_lds, idx_sub_lds);
+        double nosum = 0.0;
+        wave_gram<NT, false, LEAN>(ds, cols, k, lane, none, none, false, false, acc, idx_rows_lds, idx_sub_lds, none, nosum);
         TP_MARK(33);
         if (LEAN && shared) {
             // (issuing the first group in front of the edge rows' loop was measured and dropped: the loop's counted

@@ -50,8 +50,10 @@ def test_every_universe_size_of_the_wave_kernel(native, kernel_choice, strat):
         w_wave, s_wave, a_wave = _run(native, strat, k, N, inp)
         assert (s_wave == rstat).all() and (s_multi == rstat).all(), (k, s_wave, rstat)
         np.testing.assert_allclose(w_wave, ref, rtol=0, atol=1e-10, err_msg=f"k={k}")
-        np.testing.assert_allclose(w_wave, w_multi, rtol=0, atol=1e-12, err_msg=f"k={k}")
-        np.testing.assert_allclose(a_wave[:, :6], a_multi[:, :6], rtol=1e-12, atol=1e-300, err_msg=f"k={k}")
+        # k + 1 = 0 (mod 16): the one-wave kernel keeps the one-pass centred scatter (sums by vector adds), the multi-wave
+        # kernel its two-pass form: 2 ulp apart on S0, not the same arithmetic
+        np.testing.assert_allclose(w_wave, w_multi, rtol=0, atol=1e-11 if k % 16 == 15 else 1e-12, err_msg=f"k={k}")
+        np.testing.assert_allclose(a_wave[:, :6], a_multi[:, :6], rtol=1e-11 if k % 16 == 15 else 1e-12, atol=1e-300, err_msg=f"k={k}")
         worst = max(worst, float(np.abs(w_wave - ref).max()))
     assert worst < 1e-10
 

@@ -213,8 +213,9 @@ def test_every_universe_size_of_the_two_wave_kernel(native, strat):
             assert dev.last_launch()["block"] == (128 if k <= 191 else 256), (k, dev.last_launch())
             assert (s_two == rstat).all() and (s_multi == rstat).all(), (k, s_two, rstat)
             np.testing.assert_allclose(w_two, ref, rtol=0, atol=1e-10, err_msg=f"k={k}")
-            np.testing.assert_allclose(w_two, w_multi, rtol=0, atol=1e-12, err_msg=f"k={k}")
-            np.testing.assert_allclose(a_two[:, :6], a_multi[:, :6], rtol=1e-12, atol=1e-300, err_msg=f"k={k}")
+            # (k + 1 = 0 mod 16: one-pass centred scatter here, two-pass in the multi-wave kernel: 2 ulp apart on S0)
+            np.testing.assert_allclose(w_two, w_multi, rtol=0, atol=1e-11 if k % 16 == 15 else 1e-12, err_msg=f"k={k}")
+            np.testing.assert_allclose(a_two[:, :6], a_multi[:, :6], rtol=1e-11 if k % 16 == 15 else 1e-12, atol=1e-300, err_msg=f"k={k}")
             worst = max(worst, float(np.abs(w_two - ref).max()))
             if k >= 144:
                 dev.set_option("wave_kernel", -1)                      # the automatic pick IS the two-wave kernel there

@@ -6,12 +6,18 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from incorporating_different_sources_amd import _native, synthetic
 
-cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+# usage: phase_breakdown.py <config id | k=K> [windows] [flags]     (k=K: N=250, one intraday day; flags 4 = no shared Gram)
+arg = sys.argv[1] if len(sys.argv) > 1 else "2"
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
-shp = synthetic.config_shapes(cfg)
+flags = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+if arg.startswith("k="):
+    kk = int(arg[2:])
+    shp = dict(k=kk, N=250, n_r=249, m=77, seed=777 + kk, hf_days=1)
+else:
+    shp = synthetic.config_shapes(int(arg))
 inp = synthetic.make_kernel_inputs(shp["k"], shp["N"], W, shp["seed"], hf_days=shp["hf_days"])
 dev = _native.Device(0)
-b = dev.batch("conjugate", shp["k"], shp["N"], shp["n_r"], 5.0, W, shp["m"])
+b = dev.batch("conjugate", shp["k"], shp["N"], shp["n_r"], 5.0, W, shp["m"], flags=flags)
 b.upload(panel=inp["panel"], start=inp["start"], hf_panel=inp["hf_panel"], hf_start=inp["hf_start"], w0=inp["w0"], n0=inp["n0"])
 for _ in range(3):
     b.run()
