@@ -83,6 +83,10 @@ def parse_args():
     ap.add_argument("--hf-period", type=int, default=-1,
                     help="days after which the synthetic intraday panel wraps (0: never; default: never unless the panel "
                          "would exceed 24 GB of host memory per rank)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="tp_set_option on the handle before anything runs (A/B measurements), e.g. --opt tiled_lanes=3 "
+                         "--opt tiled_arena_mib=64 --opt wave_kernel=0")
+    ap.add_argument("--k", type=int, default=0, help="override the universe size of the config (N, n_r, m stay): sweeps")
     ap.add_argument("--rehearse-world", type=int, default=0,
                     help="run the host logic of this many ranks on however many GPUs the box has (ranks share devices, "
                          "no RCCL, host gather): a rehearsal, never a measurement")
@@ -174,6 +178,8 @@ def worker(args):
 
     config = args.config or (2 if cp.world == 1 else 4)
     shp = synthetic.config_shapes(config)
+    if args.k:
+        shp = dict(shp, k=args.k)
     k, N, n_r, m = shp["k"], shp["N"], shp["n_r"], shp["m"]
     W = args.windows or (WINDOWS_PER_RANK.get(config, shp["W"]) if cp.world > 1 else min(shp["W"], WINDOWS_PER_RANK.get(config, shp["W"])))
     conj = args.strategy == "conjugate"
@@ -189,6 +195,9 @@ def worker(args):
                                        hf_period=hf_period)
 
     dev = _native.Device(cp.local_rank % ndev if rehearsal else cp.local_rank)
+    for item in args.opt:
+        name, _, val = item.partition("=")
+        dev.set_option(name.strip(), int(val))
     gather_mode, rccl_ranks = "none", None
     if (cp.world == 1 and args.rehearse_gather) or (cp.world > 1 and not rehearsal):
         shard.init_rccl(dev, cp)            # raises -> non-zero exit: an RCCL failure is never papered over
@@ -389,12 +398,13 @@ def worker(args):
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{config - 1}]: k={k} assets, n={N}-day window, "
+            "config": {"workload": (f"BASELINE configs[{config - 1}]" if not args.k else f"shapes of configs[{config - 1}] at another universe size")
+                                   + f": k={k} assets, n={N}-day window, "
                                    f"{W} windows per GPU, {args.strategy} prior"
                                    + (f" (m={m} intraday returns, VIX-style n0)" if conj else ""),
                        "k": k, "N": N, "n_r": n_r, "m": m if conj else 0, "windows_per_gpu": W,
                        "strategy": args.strategy, "parallelism": f"windows sharded x{cp.world}",
-                       "layout": args.layout, "hf_period_days": hf_period,
+                       "layout": args.layout, "hf_period_days": hf_period, "options": args.opt,
                        "shared_gram_row_blocks": shared_blocks,
                        "gather": gather_mode, "rccl_ranks": rccl_ranks, "gather_verified": gathered_ok,
                        "rehearsal": rehearsal, "seed": shp["seed"]},

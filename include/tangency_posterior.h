@@ -137,7 +137,8 @@ int tp_destroy(tp_handle_t h);
  *   "tiled_wave"       -1 automatic | 0 four-wave Gram / diagonal-block kernels of the large-k path
  *   "tiled_fuse"       -1 automatic | 0 / 1 three-kernel / fused left-looking update of the large-k path
  *   "no_shared_gram"   1 = as if every batch carried TP_FLAG_NO_SHARED_GRAM (takes effect at the next upload)
- *   "tiled_arena_gib" / "tiled_arena_mib"  in-flight arena of the large-k path (0: default)
+ *   "tiled_arena_gib" / "tiled_arena_mib"  in-flight arena of the large-k path, per lane (0: default)
+ *   "tiled_lanes"      sub-batches of the large-k path in flight at once, each on a stream of its own (0 / 1: one)
  * Replaces nothing in the reference. */
 int tp_set_option(tp_handle_t h, const char* name, int value);
 const char* tp_last_error(tp_handle_t h); /* h may be NULL: last error of a failed tp_create */

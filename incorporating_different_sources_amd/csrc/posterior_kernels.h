@@ -125,6 +125,7 @@ struct tp_tiled_ws_t {
 int tp_tiled_max_assets(void);
 void tp_tiled_geometry(int k, int* KP, int* NS, int* NSB);
 hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStream_t stream, bool build_prefix);
+hipError_t tp_tiled_prefix_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStream_t stream);
 // bytes of the shared block Grams + n_L block-window tables of the daily panel in the tiled layout (16-row blocks)
 size_t tp_tiled_prefix_bytes(int k, long long panel_rows, int n_L, int* nblk_out);
 size_t tp_tiled_slot_doubles(int k);

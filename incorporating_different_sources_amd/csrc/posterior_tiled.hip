@@ -892,6 +892,20 @@ size_t tp_tiled_prefix_bytes(int k, long long panel_rows, int n_L, int* nblk_out
     return sizeof(double) * (size_t)nblk * (size_t)(1 + n_L) * tp_tiled_slot_doubles(k);
 }
 
+// the shared block Grams and block-window sums of a run, once per run
+hipError_t tp_tiled_prefix_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStream_t stream) {
+    const int NS = ws.NS;
+    const bool conj = a.strategy == 0;
+    const bool lean = (a.panel_off32 & (a.row_idx ? 1 : 2)) && (!conj || (a.hf_off32 & (a.hf_row_idx ? 1 : 2)));
+    if (a.winsum == nullptr || !lean) return hipSuccess;
+    hipLaunchKernelGGL(tiled_block_gram_kernel, dim3((unsigned)((long long)a.prefix_nblk * (NS * (NS + 1) / 2))), dim3(NTHREADS), 0,
+                       stream, a, ws, (double*)a.prefix);
+    int n_L = 0;
+    while (n_L < TP_WINSUM_MAX_L && a.winsum_L[n_L] > 0) ++n_L;
+    return tp_window_sums_launch(a.prefix, (double*)a.winsum, a.prefix_nblk, (size_t)(NS * (NS + 1) / 2) * SB * SB, a.winsum_L, n_L,
+                                 stream);
+}
+
 hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStream_t stream, bool build_prefix) {
     const int G = (int)a.w_count;
     if (G <= 0) return hipSuccess;
@@ -899,13 +913,8 @@ hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStre
     const bool conj = a.strategy == 0;
     // 32-bit offsets for both panels in the layout they come in (explicit rows: bit 0, contiguous: bit 1)?
     const bool lean = (a.panel_off32 & (a.row_idx ? 1 : 2)) && (!conj || (a.hf_off32 & (a.hf_row_idx ? 1 : 2)));
-    if (build_prefix && a.winsum != nullptr && lean) {      // the shared block Grams and block-window sums, once per run
-        hipLaunchKernelGGL(tiled_block_gram_kernel, dim3((unsigned)((long long)a.prefix_nblk * (NS * (NS + 1) / 2))), dim3(NTHREADS), 0,
-                           stream, a, ws, (double*)a.prefix);
-        int n_L = 0;
-        while (n_L < TP_WINSUM_MAX_L && a.winsum_L[n_L] > 0) ++n_L;
-        hipError_t e = tp_window_sums_launch(a.prefix, (double*)a.winsum, a.prefix_nblk, (size_t)(NS * (NS + 1) / 2) * SB * SB,
-                                             a.winsum_L, n_L, stream);
+    if (build_prefix) {
+        hipError_t e = tp_tiled_prefix_launch(a, ws, stream);
         if (e != hipSuccess) return e;
     }
     if (conj) {

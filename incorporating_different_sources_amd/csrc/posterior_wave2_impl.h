@@ -436,7 +436,7 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
             // row-major over the whole triangle), two 16-byte reads per tile, six tiles' reads ahead of the additions
             typedef double d2 __attribute__((ext_vector_type(2)));
             const d2* pq = (const d2*)q + lane;
-            constexpr int GRP = 6, NG = (NS + GRP - 1) / GRP;
+            constexpr int GRP = NS > 32 ? 3 : 6, NG = (NS + GRP - 1) / GRP;
             d2 qa[GRP][2], qb[GRP][2];
             auto qload = [&](d2 (&v2)[GRP][2], auto gc) __attribute__((always_inline)) {
                 constexpr int g = decltype(gc)::value;
@@ -743,8 +743,12 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
     TP_MARK(7);
 }
 
+// waves per SIMD the register allocator is asked to keep (TP_WAVE2_OCC: A/B builds; 2 needs <= 14 tiles per wave)
+#ifndef TP_WAVE2_OCC
+#define TP_WAVE2_OCC 1
+#endif
 template <int NT, int NWV, bool LEAN, int MODE>
-__global__ void __launch_bounds__(64 * NWV, 1) posterior_wave2_kernel(const tp_kargs_t A) {
+__global__ void __launch_bounds__(64 * NWV, TP_WAVE2_OCC) posterior_wave2_kernel(const tp_kargs_t A) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     wave_dispatch<NWV>(wv, [&](auto wc) __attribute__((always_inline)) {

@@ -27,6 +27,7 @@ namespace {
 thread_local std::string g_create_error;
 }
 
+#define TP_MAX_LANES 4
 struct tp_handle_s {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -54,7 +55,11 @@ struct tp_handle_s {
     tp_kopts_t opts{};
     int no_shared_gram = 0;         // TP_NO_SHARED_GRAM / "no_shared_gram"
     int tiled_arena_gib = 0;        // TP_TILED_ARENA_GIB / "tiled_arena_gib" (0: default)
-    int tiled_arena_mib = 0;        // TP_TILED_ARENA_MIB / "tiled_arena_mib": a sub-GiB arena (depth-first sub-batches)
+    int tiled_arena_mib = 0;        // TP_TILED_ARENA_MIB / "tiled_arena_mib": a sub-GiB arena per lane (depth-first sub-batches)
+    int tiled_lanes = 0;            // TP_TILED_LANES / "tiled_lanes": sub-batches in flight on streams of their own (0: default)
+    hipStream_t lane_stream[TP_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t lane_done[TP_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t lane_start = nullptr;
     int phase_limit = 0;            // TP_PHASE_LIMIT (diagnostic builds only)
     std::vector<tp_batch_t> batches;   // live batches of this handle (destroyed with it if the caller forgot them)
     // per-step kernel times inside a tp_region_begin / tp_region_end bracket: every timed launch of the region records
@@ -82,8 +87,10 @@ struct tp_batch_s {
     DevBuf prefix;                                            // shared Gram prefixes of the daily panel (register-tile path)
     int prefix_nblk = 0;                                      // > 0: the layout qualifies (decided at upload)
     int winsum_L[4] = {0, 0, 0, 0};                           // register-tile path: the whole-block counts of the windows
-    DevBuf t_arena, t_rinv, t_ybar, t_zc, t_scal, t_flags;   // large-k path workspace
-    int64_t tiled_capacity = 0;                               // windows in flight per sub-batch
+    DevBuf t_arena[TP_MAX_LANES], t_rinv[TP_MAX_LANES], t_ybar[TP_MAX_LANES], t_zc[TP_MAX_LANES], t_scal[TP_MAX_LANES],
+        t_flags[TP_MAX_LANES];                                // large-k path workspace, one per lane
+    int64_t tiled_capacity = 0;                               // windows in flight per sub-batch (per lane)
+    int tiled_lanes = 0;                                      // lanes the workspace was sized for
     bool uploaded = false;
     bool gathered = false;
     bool rhs_valid = false;                          // out_rhs was allocated before the last run (tp_batch_keep_rhs)
@@ -337,37 +344,58 @@ int validate_inputs(tp_handle_t h, const tp_params_t& p, int64_t W, const tp_inp
     return TP_OK;
 }
 
-// workspace of the large-k path, sized for as many in-flight windows as ~6 GiB allow
-int ensure_tiled_ws(tp_batch_t b, tp_tiled_ws_t* ws) {
+// Workspace of the large-k path.  Default: ONE lane whose arena holds as many in-flight windows as 32 GiB allow (fewer,
+// larger launches).  Depth-first alternative (options tiled_lanes / tiled_arena_mib): several small sub-batches in flight,
+// each on a stream and a workspace of its own, sized so that all arenas together stay inside the 256 MiB Infinity Cache
+// - the left-looking update then re-reads a window's block rows from cache instead of streaming them from HBM.
+int ensure_tiled_ws(tp_batch_t b, tp_tiled_ws_t* ws, int* lanes_out) {
     tp_handle_t h = b->h;
     int KP, NS, NSB;
     tp_tiled_geometry(b->p.k, &KP, &NS, &NSB);
     const size_t per_window = sizeof(double) * ((size_t)KP * KP + (size_t)NSB * 64 * 64 + KP + (size_t)b->p.m + 8) + 4;
+    int lanes = h->tiled_lanes >= 1 ? (h->tiled_lanes > TP_MAX_LANES ? TP_MAX_LANES : h->tiled_lanes) : 1;
     // in-flight windows of one sub-batch: an arena budget of 32 GiB of the 288 (fewer, larger launches: measured
-    // +2-4 % over 6 GiB at k = 500), never more than a third of what is free; TP_TILED_ARENA_GIB overrides it
+    // +2-4 % over 6 GiB at k = 500), never more than a third of what is free; tiled_arena_gib / _mib override it
     unsigned long long gib = 32;
     { size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (free_b >> 30) / 3 < gib) gib = (free_b >> 30) / 3 > 1 ? (free_b >> 30) / 3 : 1; }
     if (h->tiled_arena_gib >= 1 && h->tiled_arena_gib <= 200) gib = (unsigned long long)h->tiled_arena_gib;
-    unsigned long long arena_bytes = gib << 30;
+    unsigned long long arena_bytes = (gib << 30) / (unsigned long long)lanes;
     if (h->tiled_arena_mib >= 1 && h->tiled_arena_mib <= 200 * 1024) arena_bytes = (unsigned long long)h->tiled_arena_mib << 20;
     int64_t G = (int64_t)(arena_bytes / per_window);
     if (G < 1) G = 1;
     if (G > b->W) G = b->W;
     if (G > 65535) G = 65535;
-    if (b->tiled_capacity < G) {
-        int rc = ensure(h, b->t_arena, sizeof(double) * (size_t)G * KP * KP);
-        if (rc == TP_OK) rc = ensure(h, b->t_rinv, sizeof(double) * (size_t)G * NSB * 64 * 64);
-        if (rc == TP_OK) rc = ensure(h, b->t_ybar, sizeof(double) * (size_t)G * KP);
-        if (rc == TP_OK) rc = ensure(h, b->t_zc, sizeof(double) * (size_t)G * (b->p.m > 0 ? b->p.m : 1));
-        if (rc == TP_OK) rc = ensure(h, b->t_scal, sizeof(double) * (size_t)G * 8);
-        if (rc == TP_OK) rc = ensure(h, b->t_flags, sizeof(int) * (size_t)G);
-        if (rc != TP_OK) return rc;
+    if ((int64_t)lanes * G > b->W) lanes = (int)((b->W + G - 1) / G);
+    if (b->tiled_capacity < G || b->tiled_lanes < lanes) {
+        if (b->tiled_capacity > G) G = b->tiled_capacity;
+        for (int l = 0; l < lanes; ++l) {
+            int rc = ensure(h, b->t_arena[l], sizeof(double) * (size_t)G * KP * KP);
+            if (rc == TP_OK) rc = ensure(h, b->t_rinv[l], sizeof(double) * (size_t)G * NSB * 64 * 64);
+            if (rc == TP_OK) rc = ensure(h, b->t_ybar[l], sizeof(double) * (size_t)G * KP);
+            if (rc == TP_OK) rc = ensure(h, b->t_zc[l], sizeof(double) * (size_t)G * (b->p.m > 0 ? b->p.m : 1));
+            if (rc == TP_OK) rc = ensure(h, b->t_scal[l], sizeof(double) * (size_t)G * 8);
+            if (rc == TP_OK) rc = ensure(h, b->t_flags[l], sizeof(int) * (size_t)G);
+            if (rc != TP_OK) return rc;
+        }
         b->tiled_capacity = G;
+        b->tiled_lanes = lanes;
     }
-    ws->arena = (double*)b->t_arena.p; ws->rinv = (double*)b->t_rinv.p; ws->ybar = (double*)b->t_ybar.p;
-    ws->zc = (double*)b->t_zc.p; ws->scal = (double*)b->t_scal.p; ws->flags = (int*)b->t_flags.p;
-    ws->KP = KP; ws->NS = NS; ws->NSB = NSB;
+    for (int l = 0; l < lanes; ++l) {
+        ws[l].arena = (double*)b->t_arena[l].p; ws[l].rinv = (double*)b->t_rinv[l].p; ws[l].ybar = (double*)b->t_ybar[l].p;
+        ws[l].zc = (double*)b->t_zc[l].p; ws[l].scal = (double*)b->t_scal[l].p; ws[l].flags = (int*)b->t_flags[l].p;
+        ws[l].KP = KP; ws[l].NS = NS; ws[l].NSB = NSB;
+    }
+    *lanes_out = lanes;
+    return TP_OK;
+}
+
+int ensure_lane_streams(tp_handle_t h, int lanes) {
+    if (!h->lane_start) HIP_TRY(h, hipEventCreateWithFlags(&h->lane_start, hipEventDisableTiming));
+    for (int l = 0; l < lanes; ++l) {
+        if (!h->lane_stream[l]) HIP_TRY(h, hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
+        if (!h->lane_done[l]) HIP_TRY(h, hipEventCreateWithFlags(&h->lane_done[l], hipEventDisableTiming));
+    }
     return TP_OK;
 }
 
@@ -389,18 +417,35 @@ int launch(tp_batch_t b, const tp_kargs_t& a, int64_t count, bool timed) {
     }
     // large-k path: sub-batches of in-flight windows through the tiled pipeline
     if (a.dbg_S1 != nullptr) return fail(h, TP_ERR_UNSUPPORTED, "matrix read-back is not available on the large-k path");
-    tp_tiled_ws_t ws;
-    int rc = ensure_tiled_ws(b, &ws);
+    tp_tiled_ws_t ws[TP_MAX_LANES];
+    int lanes = 1;
+    int rc = ensure_tiled_ws(b, ws, &lanes);
     if (rc != TP_OK) return rc;
+    if (lanes > 1) { rc = ensure_lane_streams(h, lanes); if (rc != TP_OK) return rc; }
     if (timed) HIP_TRY(h, hipEventRecord(t0, h->stream));
-    for (int64_t w0 = 0; w0 < count; w0 += b->tiled_capacity) {
+    if (lanes > 1) {
+        // the shared sums once, on the kernel stream; then every lane's stream starts behind them
+        hipError_t e = tp_tiled_prefix_launch(a, ws[0], h->stream);
+        if (e != hipSuccess) return fail(h, TP_ERR_HIP, "tiled pipeline launch failed: %s", hipGetErrorString(e));
+        HIP_TRY(h, hipEventRecord(h->lane_start, h->stream));
+        for (int l = 0; l < lanes; ++l) HIP_TRY(h, hipStreamWaitEvent(h->lane_stream[l], h->lane_start, 0));
+    }
+    int64_t sb = 0;
+    for (int64_t w0 = 0; w0 < count; w0 += b->tiled_capacity, ++sb) {
         tp_kargs_t sub = a;
         sub.w_first = a.w_first + w0;
         sub.w_count = (count - w0 < b->tiled_capacity) ? (count - w0) : b->tiled_capacity;
-        hipError_t e = tp_tiled_launch(sub, ws, h->stream, w0 == 0);     // the shared sums once per run, not per sub-batch
+        const int l = (int)(sb % lanes);
+        hipError_t e = tp_tiled_launch(sub, ws[l], lanes > 1 ? h->lane_stream[l] : h->stream, lanes == 1 && w0 == 0);
         if (e != hipSuccess) return fail(h, TP_ERR_HIP, "tiled pipeline launch failed: %s", hipGetErrorString(e));
     }
-    h->last_launch = tp_launch_info_t{(int)(count < b->tiled_capacity ? count : b->tiled_capacity), 256, 36864, ws.NS * 4};
+    if (lanes > 1) {
+        for (int l = 0; l < lanes; ++l) {
+            HIP_TRY(h, hipEventRecord(h->lane_done[l], h->lane_stream[l]));
+            HIP_TRY(h, hipStreamWaitEvent(h->stream, h->lane_done[l], 0));
+        }
+    }
+    h->last_launch = tp_launch_info_t{(int)(count < b->tiled_capacity ? count : b->tiled_capacity), 256, 36864, ws[0].NS * 4};
     if (timed) { HIP_TRY(h, hipEventRecord(t1, h->stream)); timed_done(); }
     return TP_OK;
 }
@@ -420,7 +465,7 @@ int destroy_batch(tp_batch_t b, bool device_calls) {
         // A gather that was requested (tp_batch_gather_async) but not yet put on its stream is a collective the peer
         // ranks may already be waiting in: issue it before the buffers go away - dropping it would hang them.
         if (h->deferred == b) (void)flush_gather(h);
-        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamSynchronize(h->stream);      // (the lanes of the large-k path have joined the kernel stream)
         if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);   // a gather may still read the results
         for (hipEvent_t e : b->gather_done)
             if (e) (void)hipEventDestroy(e);
@@ -431,8 +476,10 @@ int destroy_batch(tp_batch_t b, bool device_calls) {
                          &b->panel, &b->start, &b->row_idx, &b->n_rows, &b->col_idx, &b->rf_adj, &b->hf_panel, &b->hf_start,
                          &b->hf_row_idx, &b->hf_count, &b->w0, &b->n0, &b->weights, &b->status, &b->aux, &b->dbg,
                          &b->gather_w, &b->gather_s, &b->weights2, &b->status2, &b->stamps, &b->rhs, &b->out_rhs, &b->shift,
-                         &b->prefix, &b->t_arena, &b->t_rinv, &b->t_ybar, &b->t_zc, &b->t_scal, &b->t_flags};
+                         &b->prefix};
         for (DevBuf* d : all) release(*d);
+        for (int l = 0; l < TP_MAX_LANES; ++l)
+            for (DevBuf* d : {&b->t_arena[l], &b->t_rinv[l], &b->t_ybar[l], &b->t_zc[l], &b->t_scal[l], &b->t_flags[l]}) release(*d);
     }
     if (h->deferred == b) h->deferred = nullptr;
     delete b;
@@ -455,6 +502,11 @@ int destroy_handle(tp_handle_t h, bool device_calls) {
         if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
         for (hipEvent_t e : {h->cp0, h->cp1, h->ev0, h->ev1, h->reg0, h->reg1})
             if (e) (void)hipEventDestroy(e);
+        for (int l = 0; l < TP_MAX_LANES; ++l) {
+            if (h->lane_stream[l]) { (void)hipStreamSynchronize(h->lane_stream[l]); (void)hipStreamDestroy(h->lane_stream[l]); }
+            if (h->lane_done[l]) (void)hipEventDestroy(h->lane_done[l]);
+        }
+        if (h->lane_start) (void)hipEventDestroy(h->lane_start);
         for (hipEvent_t e : h->ring0) (void)hipEventDestroy(e);
         for (hipEvent_t e : h->ring1) (void)hipEventDestroy(e);
         if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -514,6 +566,7 @@ int tp_create(int device_id, tp_handle_t* out) {
     h->no_shared_gram = getenv("TP_NO_SHARED_GRAM") != nullptr ? 1 : 0;
     h->tiled_arena_gib = env_int("TP_TILED_ARENA_GIB", 0);
     h->tiled_arena_mib = env_int("TP_TILED_ARENA_MIB", 0);
+    h->tiled_lanes = env_int("TP_TILED_LANES", 0);
     h->phase_limit = env_int("TP_PHASE_LIMIT", 0);
     {
         std::lock_guard<std::mutex> lk(g_registry_mutex);
@@ -533,6 +586,7 @@ int tp_set_option(tp_handle_t h, const char* name, int value) {
     else if (n == "no_shared_gram") h->no_shared_gram = value != 0;
     else if (n == "tiled_arena_gib") h->tiled_arena_gib = value;
     else if (n == "tiled_arena_mib") h->tiled_arena_mib = value;
+    else if (n == "tiled_lanes") h->tiled_lanes = value;
     else return fail(h, TP_ERR_INVALID, "tp_set_option: unknown option '%s'", name);
     return TP_OK;
 }
