@@ -41,9 +41,12 @@ def partition(W: int, world: int) -> list[tuple[int, int]]:
     return out
 
 
-# The register-tile kernel sums the whole aligned row blocks of a window through running sums over the panel that
-# restart every 16 blocks of 16 (or 32) rows; a shard that uploads only part of a panel must cut it at a multiple of
-# 512 rows, so that every window sees the same blocks and restarts - hence bit-identical weights - as in the full panel.
+# The register-tile kernels take the whole aligned 16-row (32-row) blocks of a window from block-window sums over the panel
+# (csrc/posterior_fused.hip, tp_window_sums_kernel).  Every sum holds the blocks of ITS window only, but the order in
+# which they are added depends on the block's position in the UPLOADED panel: windows sharded with the whole panel
+# (`run_sharded`, `bench.py`: what the product does) are bit-identical to the unsharded run; a shard that uploads only a
+# slice of the panel (this helper: tests and callers short of memory) cuts it at a multiple of 512 rows so that the 16- and
+# 32-row blocks stay the same, and agrees with the full-panel run to rounding (a few ulps of S1), not bit for bit.
 PANEL_CUT_ALIGN = 512
 
 
