@@ -456,14 +456,15 @@ def executed_from_pmc(layout, k, W, strategy, kernel_ms):
         ent = pmc["sq_counters"][layout]
         if ent["k"] != k or ent["windows"] != W or ent["strategy"] != strategy:
             return None
-        insts, busy, pmc_ms = ent["SQ_INSTS_MFMA"], ent["SQ_VALU_MFMA_BUSY_CYCLES"], ent["kernel_ms_under_pmc"]
+        insts, busy = ent["SQ_INSTS_MFMA"], ent["SQ_VALU_MFMA_BUSY_CYCLES"]
+        pmc_ms = ent.get("kernel_ms_rocprof") or kernel_ms      # duration of the same launches without counters attached
         ex_tf = insts * FLOPS_PER_MFMA_F64 / (kernel_ms * 1e-3) / 1e12
         return {"mfma_instructions_per_step": insts, "executed_tflops": ex_tf,
                 "executed_mfma_frac": ex_tf / FP64_MFMA_PEAK_TFLOPS,
                 "mfma_pipe_busy_frac": busy / (N_SIMD * pmc_ms * 1e-3 * CLOCK_HZ),
                 "source": ent.get("source", "profiles/pmc_traffic.json"),
                 "note": "SQ_INSTS_MFMA x 2048 flop / this run's kernel time / peak; SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
-                        "the profiled kernel time x 2.4 GHz)"}
+                        "the rocprofv3 --stats kernel time of the same command x 2.4 GHz)"}
     except Exception:
         return None
 

@@ -79,8 +79,12 @@ def main():
         for cs in c.values():
             for name, v in cs.items():
                 tot[name] += v
+        stats = kernel_ms(os.path.join(out_dir, "stats" if layout == "contiguous" else "stats_" + layout))
         sq[layout] = dict(k=line["config"]["k"], windows=line["config"]["windows_per_gpu"], strategy=line["config"]["strategy"],
-                          kernel_ms_under_pmc=line["roofline"]["kernel_ms"], kernels=sorted(c),
+                          kernel_ms_under_pmc=line["roofline"]["kernel_ms"],
+                          # the un-profiled duration of the same launches (rocprofv3 --kernel-trace --stats of the same command,
+                          # averages summed over the kernels of a step): the base of the pipe-busy fraction
+                          kernel_ms_rocprof=sum(stats.values()) if stats else None, kernels=sorted(c),
                           hbm_read_bytes_per_launch=sum(2048.0 * v.get("FETCH_SIZE", 0.0) for v in f2.values()) or None,
                           source=f"rocprofv3 --pmc passes of `bench.py --layout {layout} --steps 3 --warmup 1` "
                                  f"(tools/profile_round.sh), counters summed over the kernels of one step",
