@@ -13,7 +13,9 @@
 // two- / four-wave-per-window kernel (posterior_wave2_nt.hip; WAVE2_NTS)
 #define TP_WAVE_NT_MIN 1
 #define TP_WAVE_NT_MAX 9
-#define TP_WAVE2_NT_MIN 7
+#ifndef TP_WAVE2_NT_MIN
+#define TP_WAVE2_NT_MIN 10      // (the Makefile's WAVE2_NTS; 7 in A/B builds)
+#endif
 #define TP_WAVE2_NT_MAX 15
 #if TP_NT >= TP_WAVE_NT_MIN && TP_NT <= TP_WAVE_NT_MAX
 hipError_t TP_CAT(tp_wave_launch_nt, TP_NT)(const tp_kargs_t&, int, hipStream_t, tp_launch_info_t*, bool);

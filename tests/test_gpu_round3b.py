@@ -195,12 +195,11 @@ def test_every_universe_size_of_the_two_wave_kernel(native, strat):
     """EVERY k = 144 .. 239 (six tile counts; two waves per window up to 12 tiles per side, four above; every position
     of the border column inside its tile, the two-pass sizes k + 1 = 0 mod 16) on the kernel the library now picks for
     these sizes: against the oracle at the flat 1e-10 and against the multi-wave kernel it replaces (same arithmetic per
-    element up to the order of the partial sums of the back substitution: 1e-12).  Also a few sizes of the one-wave
-    kernel's range (7 .. 9 tiles per side), where the two-wave kernel is built for A/B runs."""
+    element up to the order of the partial sums of the back substitution: 1e-12)."""
     dev = native.default_device()
     worst = 0.0
     try:
-        for k in list(range(144, 240)) + [96, 100, 111, 112, 127, 128, 143]:
+        for k in range(144, 240):
             N = max(2 * k + 10, 40) if strat == "jeffreys" else max(k + 30, 40)
             inp = synthetic.make_kernel_inputs(k, N, 7, seed=41000 + k, hf_days=2 if k > 150 else 1)
             kw = _kw(inp, strat)
@@ -217,10 +216,9 @@ def test_every_universe_size_of_the_two_wave_kernel(native, strat):
             np.testing.assert_allclose(w_two, w_multi, rtol=0, atol=1e-11 if k % 16 == 15 else 1e-12, err_msg=f"k={k}")
             np.testing.assert_allclose(a_two[:, :6], a_multi[:, :6], rtol=1e-11 if k % 16 == 15 else 1e-12, atol=1e-300, err_msg=f"k={k}")
             worst = max(worst, float(np.abs(w_two - ref).max()))
-            if k >= 144:
-                dev.set_option("wave_kernel", -1)                      # the automatic pick IS the two-wave kernel there
-                w_auto, _, _ = native.posterior_batch(strat, k, N, 5.0, **kw)
-                assert np.array_equal(w_auto, w_two) and dev.last_launch()["block"] in (128, 256)
+            dev.set_option("wave_kernel", -1)                          # the automatic pick IS the two-wave kernel there
+            w_auto, _, _ = native.posterior_batch(strat, k, N, 5.0, **kw)
+            assert np.array_equal(w_auto, w_two) and dev.last_launch()["block"] in (128, 256)
     finally:
         dev.set_option("wave_kernel", -1)
     assert worst < 1e-10
