@@ -66,7 +66,18 @@ constexpr bool w2_owns_from(int WV, int I) {
     return false;
 }
 
-template <int NT_, int NWV_>
+// Which instantiations factorise in the data-flow form.  At 11 and 12 tiles per side (39 tiles per wave, seven of them in
+// VGPRs) its extra live values made the register allocator move an accumulator tile between the two register files INSIDE
+// the row loop of the general-layout conjugate kernel - a read of an MFMA result two instructions after its issue, which
+// tools/check_mfma_hazards.py rejects - so that one keeps the barrier form.  TP_WAVE2_DATAFLOW = 0 / 1 forces one form
+// everywhere (A/B builds).
+#ifdef TP_WAVE2_DATAFLOW
+constexpr bool w2_dataflow(int, bool, int) { return TP_WAVE2_DATAFLOW != 0; }
+#else
+constexpr bool w2_dataflow(int nt, bool lean, int mode) { return !((nt == 11 || nt == 12) && !lean && mode == 0); }
+#endif
+
+template <int NT_, int NWV_, bool DF_>
 struct W2Cfg {
     static constexpr int NT = NT_, NWV = NWV_;
     static constexpr int KP = 16 * NT;
@@ -77,10 +88,18 @@ struct W2Cfg {
     static constexpr int OFF_DG = OFF_M + NT * 16 * MLD;         // [16][16] diagonal tile handed to the pivot chain
     static constexpr int OFF_IDT = OFF_DG + 256;                 // [16][16] identity
     static constexpr int OFF_VEC = OFF_IDT + 256;                // [KP] column sums / Jeffreys t
-    static constexpr int OFF_RB = OFF_VEC + KP;                  // [NT][4][64] block row j in MFMA operand layout
-    static constexpr int OFF_PART = OFF_RB + NT * 256;           // [2][NWV][16] partial sums of the back substitution
+    // block row j in MFMA operand layout: tiles (j, J), j < J < NT-1, at slot J - 1 (tile (j, NT-1) is read by its owner only)
+    static constexpr int RB_TILES = NT > 2 ? NT - 2 : 1;
+    static constexpr int OFF_RB = OFF_VEC + KP;                  // [RB_TILES][4][64]
+    static constexpr int OFF_PART = OFF_RB + RB_TILES * 256;     // [2][NWV][16] partial sums of the back substitution
     static constexpr int OFF_SCAL = OFF_PART + 2 * NWV * 16;     // [16]: 0 = corner z'z, 1 = q1, 4.. = per-wave not-PD flags
-    static constexpr int LDS_DOUBLES = OFF_SCAL + 16;
+    // data-flow factorisation only (w2_dataflow(NT)): a second block-row image and diagonal buffer (steps alternate) and
+    // the flags - ints: [NT] "M_j published", then [NT][NWV] "wave w's tiles of block row j published"
+    static constexpr bool DF = DF_;
+    static constexpr int OFF_RB2 = OFF_SCAL + 16;
+    static constexpr int OFF_DG2 = OFF_RB2 + (DF ? RB_TILES * 256 : 0);
+    static constexpr int OFF_FLAG = OFF_DG2 + (DF ? 256 : 0);
+    static constexpr int LDS_DOUBLES = OFF_FLAG + (DF ? (NT * (1 + NWV) + 1) / 2 : 0);
     static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
     static constexpr int OFF_SUB = LDS_DOUBLES;                  // general layout: staged rows of the pass (wave_idx_rows)
 };
@@ -228,6 +247,26 @@ __device__ __forceinline__ void w2_gram(const WRows& src, const int* __restrict_
     w2_settle<NS>(acc);
 }
 
+// ---- data-flow synchronisation of the factorisation (flags in LDS instead of workgroup barriers) -------------------------
+// publish: every lane's LDS writes are complete (release fence = s_waitcnt lgkmcnt(0)), then lane 0 raises the flag
+__device__ __forceinline__ void w2_publish(int* flag, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) *(volatile int*)flag = 1;
+}
+// wait: spin on the flag (s_sleep between reads), then an acquire fence so that no later LDS read is moved in front of it.
+// The spin is BOUNDED (2^16 x 64 cycles, a thousand times the longest legitimate wait): a bug must never hang the GPU - the
+// window's results are then garbage and the caller sees it (the bound also raises the not-positive-definite flag).
+__device__ __forceinline__ bool w2_wait(const int* flag) {
+    int spins = 0;
+    bool ok = true;
+    while (*(const volatile int*)flag == 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 16)) { ok = false; break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return ok;
+}
+
 // general layout: panel row (and subtrahend) of every row of the pass into LDS, by all threads of the workgroup
 __device__ __forceinline__ void w2_stage_rows(const WRows& src, int tid, int nthreads, int* li, double* lsb) {
     for (int i = tid; i < src.count; i += nthreads) {
@@ -239,7 +278,7 @@ __device__ __forceinline__ void w2_stage_rows(const WRows& src, int tid, int nth
 
 template <int NT, int NWV, int WV, bool LEAN, int MODE>
 __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
-    using C = W2Cfg<NT, NWV>;
+    using C = W2Cfg<NT, NWV, w2_dataflow(NT, LEAN, MODE)>;
     constexpr int NS = w2_count<NT, NWV>(WV);
     constexpr int kI = NT - 1;
     constexpr int OWN_KI = w2_owner<NT, NWV>(kI);            // the wave that holds the border column (b, then y)
@@ -272,6 +311,10 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
         for (int i = 0; i < 4; ++i) {
             const int e = lane + 64 * i;
             lds[C::OFF_IDT + e] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
+        }
+        if constexpr (C::DF) {
+            int* fl = (int*)(lds + C::OFF_FLAG);                       // the factorisation's flags, likewise
+            for (int i = lane; i < NT * (1 + NWV); i += 64) fl[i] = 0;
         }
     }
 
@@ -537,6 +580,135 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
     TP_MARK(4);
     // ---- phase F: blocked upper Cholesky S1 = R'R with the border column riding along (y = R^-T b)
     double badacc = 0.0;
+    if constexpr (C::DF) {
+    // Data-flow form (round 3): NO workgroup barrier inside the factorisation.  The 16-pivot chains are a serial path
+    // through the block steps - chain(j+1) needs only tile (j+1, j+1) updated through step j - and with a barrier pair per
+    // step EVERY wave waited for EVERY chain (12 - 15 x ~5 k cycles: 19 % of a window's time at k = 191, 28 % at k = 223).
+    // Here the owner of column j+1 brings that one tile up to date first, runs its chain and publishes M_{j+1} while the
+    // other waves - and then itself - do the rest of step j's trailing update; waves meet only through two kinds of flags,
+    // "M_j published" and "wave w's tiles of block row j published", and the block-row image and the diagonal buffer
+    // alternate between two copies (a wave writes copy j % 2 only after its trailing update of step j-1, which needed every
+    // other wave's flag of step j-1, which each raised after finishing step j-2's reads of that copy).
+    int* mflag = (int*)(lds + C::OFF_FLAG);
+    int* rbflag = mflag + NT;
+    bool sync_ok = true;
+    auto chain = [&](auto jc) __attribute__((always_inline)) {       // tile (j, j) -> M_j = R_jj^-T, published
+        constexpr int j = decltype(jc)::value;
+        constexpr int tjj = w2_slot<NT, NWV>(j, j);
+        const int npiv = (k - 16 * j < 16) ? (k - 16 * j) : 16;
+        double* dg = lds + ((j & 1) ? C::OFF_DG2 : C::OFF_DG);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dg[(fq + 4 * r) * 16 + fr] = acc[tjj][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int c16 = lane & 15;
+        double a[16];
+        const double* src = (lane < 16) ? dg : (lds + C::OFF_IDT);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = src[i * 16 + c16];
+        constexpr bool ALL16 = j < kI;
+        double d0 = readlane_d(a[0], 0);
+        double rinv = rsqrt_cubic(d0);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            if (ALL16 || p < npiv) {
+                a[p] *= rinv;
+                badacc = fma(0.0, rinv, badacc);
+                double rinv_next = 1.0;
+                if (p + 1 < 16) {
+                    const double s1 = readlane_d(a[p], p + 1);
+                    a[p + 1] = fma(-s1, a[p], a[p + 1]);
+                    double dn = readlane_d(a[p + 1], p + 1);
+                    if (!ALL16) dn = (p + 1 < npiv) ? dn : 1.0;
+                    rinv_next = rsqrt_cubic(dn);
+                }
+#pragma unroll
+                for (int i = p + 2; i < 16; ++i) {
+                    const double sI = readlane_d(a[p], i);
+                    a[i] = fma(-sI, a[p], a[i]);
+                }
+                rinv = rinv_next;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (lane >= 16 && lane < 32) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lds[C::OFF_M + (j * 16 + i) * C::MLD + c16] = (i < npiv) ? a[i] : 0.0;
+        }
+        w2_publish(mflag + j, lane);
+    };
+    if constexpr (w2_owner<NT, NWV>(0) == WV) chain(ic<0>{});
+    static_for<0, NT>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        if (j < NTB) {
+            const int rbo = (j & 1) ? C::OFF_RB2 : C::OFF_RB;
+            // (3) this wave's tiles of block row j: R_jJ = M_j A_jJ, stored to the image for the waves that need them
+            if constexpr (w2_owns_from<NT, NWV>(WV, j)) {
+                sync_ok = w2_wait(mflag + j) && sync_ok;
+                double mop[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mop[r] = lds[C::OFF_M + (j * 16 + fr) * C::MLD + 4 * r + fq];    // M[fr][4r + fq]
+                static_for<j, NT>([&](auto Jc) __attribute__((always_inline)) {
+                    constexpr int J = decltype(Jc)::value;
+                    if constexpr (w2_owner<NT, NWV>(J) == WV && (J > j || j == kI)) {   // R_jj itself is never used again
+                        constexpr int t = w2_slot<NT, NWV>(j, J);
+                        d4 rj = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rj = __builtin_amdgcn_mfma_f64_16x16x4f64(mop[r], acc[t][r], rj, 0, 0, 0);
+                        acc[t] = rj;
+                        if constexpr (J > j && J < kI) {                 // (j, kI) is read by its owner only
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) lds[rbo + (J - 1) * 256 + r * 64 + lane] = rj[r];
+                        }
+                    }
+                });
+            }
+            w2_publish(rbflag + j * NWV + WV, lane);                   // (every wave, also one without tiles in this row)
+            if constexpr (j + 1 < NT) {
+                // the serial path first: the next diagonal tile and its chain (operands of this wave only)
+                constexpr bool OWN_NEXT = w2_owner<NT, NWV>(j + 1) == WV;
+                if constexpr (OWN_NEXT) {
+                    constexpr int t = w2_slot<NT, NWV>(j + 1, j + 1), tJ = w2_slot<NT, NWV>(j, j + 1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[tJ][r], acc[tJ][r], acc[t], 0, 0, 1);
+                    if (j + 1 < NTB) chain(ic<j + 1>{});
+                }
+                // (4) the rest of the trailing update A_IJ -= R_jI' R_jJ: it needs the other waves' tiles of block row j
+                static_for<0, NWV>([&](auto vc) __attribute__((always_inline)) {
+                    constexpr int v = decltype(vc)::value;
+                    if constexpr (v != WV) sync_ok = w2_wait(rbflag + j * NWV + v) && sync_ok;
+                });
+                static_for<j + 1, NT>([&](auto Ic) __attribute__((always_inline)) {
+                    constexpr int I = decltype(Ic)::value;
+                    if constexpr (w2_owns_from<NT, NWV>(WV, I)) {
+                        double aI[4];
+                        if constexpr (w2_owner<NT, NWV>(I) == WV) {
+                            constexpr int tI = w2_slot<NT, NWV>(j, I);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) aI[r] = acc[tI][r];
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) aI[r] = lds[rbo + (I - 1) * 256 + r * 64 + lane];
+                        }
+                        static_for<I, NT>([&](auto Jc) __attribute__((always_inline)) {
+                            constexpr int J = decltype(Jc)::value;
+                            if constexpr (w2_owner<NT, NWV>(J) == WV && !(OWN_NEXT && I == j + 1 && J == j + 1)) {
+                                constexpr int t = w2_slot<NT, NWV>(I, J), tJ = w2_slot<NT, NWV>(j, J);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aI[r], acc[tJ][r], acc[t], 0, 0, 1);
+                            }
+                        });
+                    }
+                });
+            }
+        }
+    });
+    if (!sync_ok) badacc = __builtin_nan("");                          // (never in a correct run: see w2_wait)
+    __syncthreads();                                                   // every wave has left the factorisation
+    } else {
+    // barrier form: the owner of the diagonal tile runs the chain while every other wave waits (A/B builds)
     static_for<0, NT>([&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
         if (j < NTB) {
@@ -602,7 +774,7 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
                         acc[t] = rj;
                         if constexpr (J > j && J < kI) {                 // (j, kI) is read by its owner only
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) lds[C::OFF_RB + J * 256 + r * 64 + lane] = rj[r];
+                            for (int r = 0; r < 4; ++r) lds[C::OFF_RB + (J - 1) * 256 + r * 64 + lane] = rj[r];
                         }
                     }
                 });
@@ -621,7 +793,7 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
                             for (int r = 0; r < 4; ++r) aI[r] = acc[tI][r];
                         } else {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) aI[r] = lds[C::OFF_RB + I * 256 + r * 64 + lane];
+                            for (int r = 0; r < 4; ++r) aI[r] = lds[C::OFF_RB + (I - 1) * 256 + r * 64 + lane];
                         }
                         static_for<I, NT>([&](auto Jc) __attribute__((always_inline)) {
                             constexpr int J = decltype(Jc)::value;
@@ -637,6 +809,8 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
             }
         }
     });
+
+    }
 
     TP_MARK(5);
     // ---- phase G: y, q1 = y'y (ref:574), back substitution R w = y along block rows
@@ -756,14 +930,14 @@ __global__ void __launch_bounds__(64 * NWV, TP_WAVE2_OCC) posterior_wave2_kernel
     });
 }
 
-template <int NT, int NWV, bool LEAN>
+template <int NT, int NWV, bool LEAN, int MODE>
 inline int wave2_lds_bytes(const tp_kargs_t& a) {
-    return W2Cfg<NT, NWV>::LDS_BYTES + (LEAN ? 0 : wave_idx_bytes(a.n_r, a.m, a.strategy == 0));
+    return W2Cfg<NT, NWV, w2_dataflow(NT, LEAN, MODE)>::LDS_BYTES + (LEAN ? 0 : wave_idx_bytes(a.n_r, a.m, a.strategy == 0));
 }
 
 template <int NT, int NWV, bool LEAN, int MODE>
 hipError_t wave2_launch_mode(const tp_kargs_t& a, int grid8, hipStream_t stream) {
-    const int lds_bytes = wave2_lds_bytes<NT, NWV, LEAN>(a);
+    const int lds_bytes = wave2_lds_bytes<NT, NWV, LEAN, MODE>(a);
     if (lds_bytes > WAVE2_LDS_LIMIT) return hipErrorNotSupported;     // nothing launched: launch_one falls back
     static std::atomic<unsigned long long> attr_done{0};      // one bit per device (tp_allow_dynamic_lds)
     { hipError_t e = tp_allow_dynamic_lds(attr_done, posterior_wave2_kernel<NT, NWV, LEAN, MODE>, WAVE2_LDS_LIMIT); if (e != hipSuccess) return e; }
@@ -773,7 +947,10 @@ hipError_t wave2_launch_mode(const tp_kargs_t& a, int grid8, hipStream_t stream)
 
 template <int NT, int NWV, bool LEAN>
 hipError_t wave2_launch_variant(const tp_kargs_t& a, int grid, hipStream_t stream, tp_launch_info_t* info) {
-    if (info) { info->grid = grid; info->block = 64 * NWV; info->lds_bytes = wave2_lds_bytes<NT, NWV, LEAN>(a); info->ntile = NT; }
+    if (info) {
+        info->grid = grid; info->block = 64 * NWV; info->ntile = NT;
+        info->lds_bytes = wave_mode(a) == 1 ? wave2_lds_bytes<NT, NWV, LEAN, 1>(a) : wave2_lds_bytes<NT, NWV, LEAN, 0>(a);
+    }
     const int grid8 = 8 * ((grid + 7) / 8);
     switch (wave_mode(a)) {
         case 0: return wave2_launch_mode<NT, NWV, LEAN, 0>(a, grid8, stream);
