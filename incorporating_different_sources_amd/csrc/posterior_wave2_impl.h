@@ -125,7 +125,7 @@ __device__ __forceinline__ void w2_settle(d4 (&acc)[N]) {
 // One pass over the rows of a window for wave WV: acc(I, J) += rows[:, I]' rows[:, J] for its own tile columns J.
 // Everything else as wave_gram (posterior_wave_impl.h).
 template <int NT, int NWV, int WV, bool HF, bool LEAN>
-__device__ __forceinline__ void w2_gram(const WRows& src, const int* __restrict__ cols, int k, int lane,
+__device__ __forceinline__ void w2_gram(const WRows& src, const long long (&coff)[NT], int k, int lane,
                                         double (&shift)[NT], double (&w0v)[NT], bool ones, bool lazy_mask,
                                         d4 (&acc)[w2_count<NT, NWV>(WV)], const int* lds_rows, const double* lds_sub,
                                         double (&csum)[NT], double& usum) {
@@ -138,13 +138,6 @@ __device__ __forceinline__ void w2_gram(const WRows& src, const int* __restrict_
     const int nks = (src.count + 3) >> 2;
     const bool has_sub = !HF && src.sub_row != nullptr;
 
-    long long coff[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int c = 16 * i + fr;
-        const int cl = c < k ? c : k - 1;
-        coff[i] = (!LEAN && cols) ? (long long)cols[cl] : (long long)cl;
-    }
     int row_pref = 0;
     double sub_pref = 0.0;
     auto prefetch = [&](int ks) __attribute__((always_inline)) {
@@ -254,14 +247,15 @@ __device__ __forceinline__ void w2_publish(int* flag, int lane) {
     if (lane == 0) *(volatile int*)flag = 1;
 }
 // wait: spin on the flag (s_sleep between reads), then an acquire fence so that no later LDS read is moved in front of it.
-// The spin is BOUNDED (2^16 x 64 cycles, a thousand times the longest legitimate wait): a bug must never hang the GPU - the
-// window's results are then garbage and the caller sees it (the bound also raises the not-positive-definite flag).
+// The spin is BOUNDED (2^20 iterations of >= 64 cycles: tens of milliseconds, ten thousand times the longest legitimate
+// wait): a bug must never hang the GPU - the window's results are then garbage and the caller sees it (the bound also
+// raises the not-positive-definite flag).
 __device__ __forceinline__ bool w2_wait(const int* flag) {
     int spins = 0;
     bool ok = true;
     while (*(const volatile int*)flag == 0) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 16)) { ok = false; break; }
+        if (++spins > (1 << 20)) { ok = false; break; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     return ok;
@@ -300,6 +294,25 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
     (void)tid0;
 
     const int* cols = (!LEAN && A.col_idx) ? A.col_idx + w * k : nullptr;
+    // column offsets (doubles) of this lane in the NT column groups, once per window; padding columns re-read column k-1.
+    // The gathered columns' indices are requested together (one wait), not one dependent load per select.
+    long long coff[NT];
+    if (cols != nullptr) {
+        int cidx[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int c = 16 * i + fr;
+            cidx[i] = cols[c < k ? c : k - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) coff[i] = (long long)cidx[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int c = 16 * i + fr;
+            coff[i] = (long long)(c < k ? c : k - 1);
+        }
+    }
     double* idx_sub_lds = LEAN ? nullptr : lds + C::OFF_SUB;
     int* idx_rows_lds = LEAN ? nullptr : (int*)(lds + C::OFF_SUB + wave_idx_rows(A.n_r, A.m, A.strategy == 0));
     d4 acc[NS];
@@ -342,7 +355,7 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
             for (int i = 0; i < NT; ++i) {
                 const int c = 16 * i + fr;
                 const int cl = c < k ? c : k - 1;
-                shift[i] = p0[cols ? cols[cl] : cl];
+                shift[i] = p0[coff[i]];
                 w0v[i] = A.w0[w * k + cl];
                 csum[i] = 0.0;
             }
@@ -353,7 +366,7 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
         if (!hs.ridx) { hs.first += 1; hs.count -= 1; }
         else { hs.ridx += 1; hs.count -= 1; }
         if constexpr (!LEAN) w2_stage_rows(hs, tid, C::NTHREADS, idx_rows_lds, idx_sub_lds);
-        w2_gram<NT, NWV, WV, true, LEAN>(hs, cols, k, lane, shift, w0v, ones, true, acc, idx_rows_lds, idx_sub_lds, csum, usum);
+        w2_gram<NT, NWV, WV, true, LEAN>(hs, coff, k, lane, shift, w0v, ones, true, acc, idx_rows_lds, idx_sub_lds, csum, usum);
         hs.count = hf_rows_all;
         TP_MARK(2);
         // ---- phase C: rank-one term of the centring, q0, c, scaling (ref:333, 415-418)
@@ -472,7 +485,7 @@ __device__ __forceinline__ void w2_body(const tp_kargs_t& A, double* lds) {
         if constexpr (!LEAN) w2_stage_rows(ds, tid, C::NTHREADS, idx_rows_lds, idx_sub_lds);
         TP_MARK(32);
         double nosum = 0.0;
-        w2_gram<NT, NWV, WV, false, LEAN>(ds, cols, k, lane, none, none, false, false, acc, idx_rows_lds, idx_sub_lds, none, nosum);
+        w2_gram<NT, NWV, WV, false, LEAN>(ds, coff, k, lane, none, none, false, false, acc, idx_rows_lds, idx_sub_lds, none, nosum);
         TP_MARK(33);
         if (LEAN && shared) {
             // this wave's tiles of the table slot Q_L[b0]: [tile][2][64 lanes][2] doubles (the table numbers the tiles

@@ -130,7 +130,7 @@ struct WRows {
 //  wave has nothing else to run meanwhile)
 //  !LEAN: lds_rows[r] / lds_sub[r] hold the panel row and the subtrahend of row r of this pass (staged by wave_stage_rows)
 template <int NT, bool HF, bool LEAN>
-__device__ __forceinline__ void wave_gram(const WRows& src, const int* __restrict__ cols, int k, int lane,
+__device__ __forceinline__ void wave_gram(const WRows& src, const long long (&coff)[NT], int k, int lane,
                                           double (&shift)[NT], double (&w0v)[NT], bool ones, bool lazy_mask,
                                           d4 (&acc)[WCfg<NT>::NTILES], const int* lds_rows, const double* lds_sub,
                                           double (&csum)[NT], double& usum) {
@@ -143,13 +143,6 @@ __device__ __forceinline__ void wave_gram(const WRows& src, const int* __restric
     const bool has_sub = !HF && src.sub_row != nullptr;
 
     // column offsets (doubles) of this lane in the NT column groups; padding columns re-read column k-1
-    long long coff[NT];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int c = 16 * i + fr;
-        const int cl = c < k ? c : k - 1;
-        coff[i] = (!LEAN && cols) ? (long long)cols[cl] : (long long)cl;
-    }
     // general layout: the pass's panel rows (and subtrahends) come from LDS; the values of the NEXT load are fetched right
     // behind the current load's requests, a whole k-step of MFMAs ahead of their use
     int row_pref = 0;
@@ -295,6 +288,25 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
     (void)tid0;
 
     const int* cols = (!LEAN && A.col_idx) ? A.col_idx + w * k : nullptr;
+    // column offsets (doubles) of this lane in the NT column groups, once per window; padding columns re-read column k-1.
+    // The gathered columns' indices are requested together (one wait), not one dependent load per select.
+    long long coff[NT];
+    if (cols != nullptr) {
+        int cidx[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int c = 16 * i + fr;
+            cidx[i] = cols[c < k ? c : k - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) coff[i] = (long long)cidx[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int c = 16 * i + fr;
+            coff[i] = (long long)(c < k ? c : k - 1);
+        }
+    }
     // general layout: staging region of the pass in flight behind the fixed part of the LDS image
     double* idx_sub_lds = LEAN ? nullptr : lds + C::OFF_SUB;
     int* idx_rows_lds = LEAN ? nullptr : (int*)(lds + C::OFF_SUB + wave_idx_rows(A.n_r, A.m, A.strategy == 0));
@@ -367,7 +379,7 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
             for (int i = 0; i < NT; ++i) {
                 const int c = 16 * i + fr;
                 const int cl = c < k ? c : k - 1;
-                const double sv = p0[cols ? cols[cl] : cl];
+                const double sv = p0[coff[i]];
                 const double wv = A.w0[w * k + cl];
                 shift[i] = sv;               // raw: zeroed beyond column k inside wave_gram (lazy_mask)
                 w0v[i] = wv;
@@ -382,7 +394,7 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
         if (!hs.ridx) { hs.first += 1; hs.count -= 1; }
         else { hs.ridx += 1; hs.count -= 1; }
         if constexpr (!LEAN) wave_stage_rows(hs, lane, idx_rows_lds, idx_sub_lds);      // (WCfg::OFF_SUB)
-        wave_gram<NT, true, LEAN>(hs, cols, k, lane, shift, w0v, ones, true, acc, idx_rows_lds, idx_sub_lds, csum, usum);
+        wave_gram<NT, true, LEAN>(hs, coff, k, lane, shift, w0v, ones, true, acc, idx_rows_lds, idx_sub_lds, csum, usum);
         hs.count = hf_rows_all;
         TP_MARK(2);
         // ---- phase C: rank-one term of the centring (one-pass form); q0, c, scaling (ref:333, 415-418).  ONE pass over
@@ -523,7 +535,7 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
         // (every load of the intraday pass has completed: its staging region is free for the daily pass)
         if constexpr (!LEAN) wave_stage_rows(ds, lane, idx_rows_lds, idx_sub_lds);
         double nosum = 0.0;
-        wave_gram<NT, false, LEAN>(ds, cols, k, lane, none, none, false, false, acc, idx_rows_lds, idx_sub_lds, none, nosum);
+        wave_gram<NT, false, LEAN>(ds, coff, k, lane, none, none, false, false, acc, idx_rows_lds, idx_sub_lds, none, nosum);
         TP_MARK(33);
         if (LEAN && shared) {
             // (issuing the first group in front of the edge rows' loop was measured and dropped: the loop's counted
