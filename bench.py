@@ -353,7 +353,7 @@ def worker(args):
             g_launch = dev.last_launch()
             g_tf = alg_flops_per_window(k, n_r, m, conj) * W / (g_ms * 1e-3) / 1e12
             general[layout.replace("-", "_")] = {
-                "windows_per_s": W / g_wall, "kernel_ms": g_ms, "step_ms_median": float(np.median(gs)) if len(gs) else None,
+                "windows_per_s": W / (g_ms * 1e-3), "wall_windows_per_s": W / g_wall, "kernel_ms": g_ms, "step_ms_median": float(np.median(gs)) if len(gs) else None,
                 "steps": gsteps, "shared_gram_row_blocks": gb.shared_gram_blocks(),
                 "roofline_frac": g_tf / FP64_MFMA_PEAK_TFLOPS, "achieved_tflops": g_tf,
                 "kernel": register_tile_kernel(g_launch) if k <= 239 else "tiled pipeline",
