@@ -134,7 +134,8 @@ int tp_destroy(tp_handle_t h);
  * (TP_WAVE_KERNEL, TP_TILED_WAVE, TP_TILED_FUSE, TP_NO_SHARED_GRAM, TP_TILED_ARENA_GIB, TP_TILED_ARENA_MIB) are read
  * ONCE, in tp_create; afterwards only this call changes them - no launch reads the environment.
  *   "wave_kernel"      -1 automatic | 0 multi-wave register-tile kernel | 1 one-wave kernel | 2 two-wave kernel
- *   "tiled_wave"       -1 automatic | 0 four-wave Gram / diagonal-block kernels of the large-k path
+ *   "tiled_wave"       -1 automatic | 0 four-wave Gram / diagonal-block kernels of the large-k path | 2 Gram with
+ *                      two super-tiles per wavefront
  *   "tiled_fuse"       -1 automatic | 0 / 1 three-kernel / fused left-looking update of the large-k path
  *   "no_shared_gram"   1 = as if every batch carried TP_FLAG_NO_SHARED_GRAM (takes effect at the next upload)
  *   "tiled_arena_gib" / "tiled_arena_mib"  in-flight arena of the large-k path, per lane (0: default)

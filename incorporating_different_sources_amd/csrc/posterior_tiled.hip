@@ -925,7 +925,11 @@ hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStre
     }
     // one wavefront per super-tile (posterior_tiled_wave.h) unless TP_TILED_WAVE=0 asks for the 4-wave kernels (A/B runs)
     const bool use_wave = a.opts.tiled_wave != 0;
-    if (use_wave)
+    if (a.opts.tiled_wave == 2) {             // 64 x 128 per wavefront (A/B: option tiled_wave = 2)
+        int np = 0;
+        for (int i = 0; i < NS; ++i) np += (NS - i + 1) / 2;
+        hipLaunchKernelGGL(tiled_gram_wave_pair_kernel, xcd_grid(np, G), dim3(64), 0, stream, a, ws, np);
+    } else if (use_wave)
         hipLaunchKernelGGL(tiled_gram_wave_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(64), 0, stream, a, ws);
     else if (lean) hipLaunchKernelGGL(tiled_gram_lean_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws);
     else hipLaunchKernelGGL(tile64_kernel<MODE_GRAM>, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws, 0);

@@ -34,11 +34,13 @@ __device__ __forceinline__ void tw_settle8(d4& c0, d4& c1, d4& c2, d4& c3, d4& c
 // One pass over rows: acc(a, b) += rows[:, A group a]' rows[:, B group b], a, b = 0..3, 4 rows per k-step.
 //  HF:  intraday rows sqrt(s) (y - ybar), border column c sqrt(s) z_r (ref:317-333, 489)
 //  !HF: daily rows minus the risk-free adjustment, border column 1 (ref:57, 180, 222)
-template <bool DIAG, bool EDGE, bool HF>
-__device__ __forceinline__ void tw_gram_pass(const TRows& src, const long long (&co)[8], const double (&yb)[8],
-                                             const bool (&cval)[8], const bool (&cbord)[8], const double sqs, const int lane,
-                                             d4 (&acc)[16]) {
-    constexpr int NO = DIAG ? 4 : 8;            // operand registers per k-step (a diagonal super-tile: A = B)
+//  NB: 16-column B groups per k-step: 4 = one 64 x 64 super-tile, 8 = two super-tiles side by side (64 x 128, the pair
+//  kernel: the A operands are loaded once for both)
+template <bool DIAG, bool EDGE, bool HF, int NB>
+__device__ __forceinline__ void tw_gram_pass(const TRows& src, const long long (&co)[4 + NB], const double (&yb)[4 + NB],
+                                             const bool (&cval)[4 + NB], const bool (&cbord)[4 + NB], const double sqs, const int lane,
+                                             d4 (&acc)[4 * NB]) {
+    constexpr int NO = DIAG ? NB : 4 + NB;      // operand registers per k-step (a diagonal super-tile: its B groups are the A groups)
     const int fq = lane >> 4;
     const int nks = (src.count + 3) >> 2;
     const bool has_c = src.rowc != nullptr;
@@ -78,11 +80,11 @@ __device__ __forceinline__ void tw_gram_pass(const TRows& src, const long long (
         }
         static_for_t<0, 4>([&](auto ac) __attribute__((always_inline)) {
             constexpr int a = decltype(ac)::value;
-            static_for_t<0, 4>([&](auto bc) __attribute__((always_inline)) {
+            static_for_t<0, NB>([&](auto bc) __attribute__((always_inline)) {
                 constexpr int b = decltype(bc)::value;
                 // a diagonal super-tile: the tiles below its diagonal are never read (the diagonal-block kernel and the
                 // left-looking update use column >= row only) - 10 MFMAs per k-step instead of 16
-                if constexpr (!DIAG || a <= b) tw_mfma_agpr(acc[4 * a + b], v[a], v[DIAG ? b : 4 + b]);
+                if constexpr (!DIAG || a <= b) tw_mfma_agpr(acc[NB * a + b], v[a], v[DIAG ? b : 4 + b]);
             });
         });
     };
@@ -91,7 +93,7 @@ __device__ __forceinline__ void tw_gram_pass(const TRows& src, const long long (
     double ra = 0.0, rb = 0.0, rc = 0.0;
     load(va, ra, 0);
     load(vb, rb, 1);
-    static_for_t<0, 16>([&](auto tc) __attribute__((always_inline)) { tw_pin1(acc[decltype(tc)::value]); });
+    static_for_t<0, 4 * NB>([&](auto tc) __attribute__((always_inline)) { tw_pin1(acc[decltype(tc)::value]); });
     int ks = 0;
 #pragma nounroll
     for (; 4 * (ks + 3) <= src.count; ks += 3) {
@@ -108,13 +110,19 @@ __device__ __forceinline__ void tw_gram_pass(const TRows& src, const long long (
         if (ks + 1 < nks) step(vb, rb, ks + 1, std::integral_constant<int, 1>{});
         if (ks + 2 < nks) step(vc, rc, ks + 2, std::integral_constant<int, 1>{});
     }
-    tw_settle8(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
-    tw_settle8(acc[8], acc[9], acc[10], acc[11], acc[12], acc[13], acc[14], acc[15]);
+    static_for_t<0, NB / 2>([&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = 8 * decltype(gc)::value;
+        tw_settle8(acc[g], acc[g + 1], acc[g + 2], acc[g + 3], acc[g + 4], acc[g + 5], acc[g + 6], acc[g + 7]);
+    });
 }
 
-template <bool DIAG, bool EDGE>
+// PAIR: the wave owns super-tiles (SI, SJ) AND (SI, SJ + 1): 32 tiles = all 256 AGPRs, one wave per SIMD, 12 operand loads
+// and 32 MFMAs per k-step (a diagonal pair: 8 loads, 26 MFMAs) instead of 2 x (8 loads, 16 MFMAs)
+template <bool DIAG, bool EDGE, bool PAIR = false>
 __device__ __forceinline__ void gram64_wave_body(const tp_kargs_t& A, const tp_tiled_ws_t& ws, const long long wl, const int SI,
                                                  const int SJ) {
+    constexpr int NB = PAIR ? 8 : 4;
+    constexpr int NC = 4 + NB;
     const int lane = threadIdx.x;
     const int fr = lane & 15, fq = lane >> 4;
     const long long w = A.w_first + wl;
@@ -127,20 +135,23 @@ __device__ __forceinline__ void gram64_wave_body(const tp_kargs_t& A, const tp_t
     const double sqs = conj ? ws.scal[wl * 8 + 1] : 0.0;
     const double* ybar = ws.ybar + wl * KP;
 
-    long long co[8];
-    double yb[8];
-    bool cval[8], cbord[8];
+    long long co[NC];
+    double yb[NC];
+    bool cval[NC], cbord[NC];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int gc = 64 * ((i >> 2) ? SJ : SI) + fr + 16 * (i & 3);
+    for (int i = 0; i < NC; ++i) {
+        // operand groups 0..3: the A groups (super-tile column SI); 4..: the B groups of SJ (and SJ + 1).  A diagonal
+        // super-tile uses the first NB entries only: SI's groups, then (pair) those of SI + 1
+        const int st = DIAG ? SI + (i >> 2) : (i < 4 ? SI : SJ + ((i - 4) >> 2));
+        const int gc = 64 * st + fr + 16 * (i & 3);
         cval[i] = !EDGE || gc < k;
         cbord[i] = EDGE && gc == k;
         const int gcl = cval[i] ? gc : k - 1;                      // padding columns re-read column k-1 (masked)
         co[i] = cols ? (long long)cols[gcl] : (long long)gcl;
         yb[i] = (conj && cval[i]) ? ybar[gcl] : 0.0;
     }
-    d4 acc[16];
-    static_for_t<0, 16>([&](auto tc) __attribute__((always_inline)) {
+    d4 acc[4 * NB];
+    static_for_t<0, 4 * NB>([&](auto tc) __attribute__((always_inline)) {
         acc[decltype(tc)::value] = d4{0.0, 0.0, 0.0, 0.0};
         tw_pin1(acc[decltype(tc)::value]);
     });
@@ -152,7 +163,7 @@ __device__ __forceinline__ void gram64_wave_body(const tp_kargs_t& A, const tp_t
         hs.first = A.hf_start ? A.hf_start[w] : 0;
         hs.rowc = ws.zc + wl * (long long)A.m;
         hs.count = mm; hs.count0 = 0x7fffffff; hs.jump = 0;
-        tw_gram_pass<DIAG, EDGE, true>(hs, co, yb, cval, cbord, sqs, lane, acc);
+        tw_gram_pass<DIAG, EDGE, true, NB>(hs, co, yb, cval, cbord, sqs, lane, acc);
     }
     // daily rows; with the shared block-window sums only the rows in front of the first whole aligned block and behind
     // the last one (see gram64_lean_body)
@@ -171,26 +182,27 @@ __device__ __forceinline__ void gram64_wave_body(const tp_kargs_t& A, const tp_t
         ds.jump = (int)(CH * pb1 - ds.first) - ds.count0;
         ds.count = ds.count0 + (int)(ds.first + nr - CH * pb1);
     }
-    tw_gram_pass<DIAG, EDGE, false>(ds, co, yb, cval, cbord, sqs, lane, acc);
+    tw_gram_pass<DIAG, EDGE, false, NB>(ds, co, yb, cval, cbord, sqs, lane, acc);
 
     // the table slot (tile row a of the super-tile at a time) and the store to the arena
     typedef double d2 __attribute__((ext_vector_type(2)));
     const long long ntile = (long long)ws.NS * (ws.NS + 1) / 2;
+    // (the super-tiles of a pair are neighbours in the row-major numbering of the triangle: slot of (SI, SJ + 1) = slot + 1)
     const d2* q = shared ? (const d2*)(A.winsum + (((long long)li * A.prefix_nblk + pb0) * ntile + pair_index(SI, SJ, ws.NS)) * (SB * SB)) + lane
                          : nullptr;
     static_for_t<0, 4>([&](auto ac) __attribute__((always_inline)) {
         constexpr int a = decltype(ac)::value;
-        d2 v2[4][2];
+        d2 v2[NB][2];
         if (shared) {
             // [..][tile row a][16-column group b][2][64 lanes][2]: registers (0,1) and (2,3) of a lane are 16 contiguous bytes
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) v2[b][h] = q[a * 512 + (b * 2 + h) * 64];
+                for (int h = 0; h < 2; ++h) v2[b][h] = q[(b >> 2) * (SB * SB / 2) + a * 512 + ((b & 3) * 2 + h) * 64];
         }
-        static_for_t<0, 4>([&](auto bc) __attribute__((always_inline)) {
+        static_for_t<0, NB>([&](auto bc) __attribute__((always_inline)) {
             constexpr int b = decltype(bc)::value;
-            d4 x = acc[4 * a + b];               // (below the diagonal of a diagonal super-tile: the zeros it started with)
+            d4 x = acc[NB * a + b];              // (below the diagonal of a diagonal super-tile: the zeros it started with)
             if (shared && (!DIAG || a <= b)) {
                 x[0] += v2[b][0][0]; x[1] += v2[b][0][1];
                 x[2] += v2[b][1][0]; x[3] += v2[b][1][1];
@@ -214,6 +226,43 @@ __global__ void __launch_bounds__(64, 2) tiled_gram_wave_kernel(const tp_kargs_t
     } else {
         if (edge) gram64_wave_body<false, true>(A, ws, wl, SI, SJ);
         else gram64_wave_body<false, false>(A, ws, wl, SI, SJ);
+    }
+}
+
+// 64 x 128 per wavefront: super-tiles (I, J) and (I, J + 1) of a window, J = I, I + 2, ... (a single one at the end of an odd
+// row).  Half the waves, each with all 256 AGPRs, ONE per SIMD: the 70 % matrix-pipe utilisation of the 64 x 64 form comes
+// with two waves per SIMD whose vector / load phases do not hide under each other's MFMAs (MI355X: a wave streaming fp64
+// MFMAs leaves its SIMD partner one vector instruction per MFMA); here a k-step is 32 MFMAs (2,048 cycles) for 12 loads.
+__device__ __forceinline__ int tw_pair_count(int NS) { int n = 0; for (int i = 0; i < NS; ++i) n += (NS - i + 1) / 2; return n; }
+__device__ __forceinline__ void tw_pair_decode(int p, int NS, int& SI, int& SJ, bool& two) {
+    int i = 0, rem = p;
+    while (rem >= (NS - i + 1) / 2) { rem -= (NS - i + 1) / 2; ++i; }
+    SI = i; SJ = i + 2 * rem; two = SJ + 1 < NS;
+}
+__global__ void __launch_bounds__(64, 1) tiled_gram_wave_pair_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws, const int NP) {
+    long long wl;
+    int tile, SI, SJ;
+    bool two;
+    if (!xcd_window_tile(NP, A.w_count, wl, tile)) return;
+    tw_pair_decode(tile, ws.NS, SI, SJ, two);
+    const int last = SJ + (two ? 1 : 0);
+    const bool edge = !(64 * last + 63 < A.k);
+    if (two) {
+        if (SI == SJ) {
+            if (edge) gram64_wave_body<true, true, true>(A, ws, wl, SI, SJ);
+            else gram64_wave_body<true, false, true>(A, ws, wl, SI, SJ);
+        } else {
+            if (edge) gram64_wave_body<false, true, true>(A, ws, wl, SI, SJ);
+            else gram64_wave_body<false, false, true>(A, ws, wl, SI, SJ);
+        }
+    } else {
+        if (SI == SJ) {
+            if (edge) gram64_wave_body<true, true>(A, ws, wl, SI, SJ);
+            else gram64_wave_body<true, false>(A, ws, wl, SI, SJ);
+        } else {
+            if (edge) gram64_wave_body<false, true>(A, ws, wl, SI, SJ);
+            else gram64_wave_body<false, false>(A, ws, wl, SI, SJ);
+        }
     }
 }
 
