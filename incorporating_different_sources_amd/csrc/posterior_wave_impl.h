@@ -118,6 +118,7 @@ struct WRows {
     int count;              // rows
     int count0;             // contiguous, two row ranges: staged rows r >= count0 are panel rows first + r + jump
     int jump;
+    bool off32 = false;     // general layout: row * 8 ld + 8 column fits 32 bits for every row of the PANEL (host-checked)
 };
 
 // One pass over the rows of a window: acc(I,J) += rows[:, I]' rows[:, J], 4 rows per k-step.
@@ -154,15 +155,38 @@ __device__ __forceinline__ void wave_gram(const WRows& src, const long long (&co
         if (has_sub) sub_pref = lds_sub[r];
     };
     if constexpr (!LEAN) prefetch(0);
+    // 32-bit addressing: a wave-uniform 64-bit base (the window's first row; general layout: the panel) + row * (8 ld) +
+    // 8 column, ONE 24-bit multiply-add per operand (the 64-bit row * ld product cost 15 vector instructions per k-step).
+    // The contiguous layout always qualifies (tp_layout_is_lean); the general layout when the panel is below 4 GiB
+    // (tp_kargs_t::panel_off32 / hf_off32 bit 0), else it keeps 64-bit addresses.
+    const char* ub = (const char*)(LEAN ? src.base + src.first * src.ld : src.base);
+    const unsigned ld8 = (unsigned)src.ld * 8u;
+    unsigned c8[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) c8[i] = 8u * (unsigned)coff[i];
     auto load = [&](double (&v)[NT], double& sub, int ks) __attribute__((always_inline)) {
         int r = 4 * ks + fq;
         r = r < src.count ? r : src.count - 1;                      // rows past the end re-read the last row (masked below)
-        long long row;
-        if constexpr (LEAN) row = src.first + r + (r >= src.count0 ? src.jump : 0);
-        else row = (long long)row_pref;
-        const double* p = src.base + row * src.ld;
+        if (LEAN || src.off32) {
+            unsigned row;
+            if constexpr (LEAN) row = (unsigned)(r + (r >= src.count0 ? src.jump : 0));
+            else row = (unsigned)row_pref;
+            if constexpr (LEAN) {
+                // ungathered columns: group i sits 128 i bytes behind group 0 (immediate offsets); only the last group clamps
+                const unsigned r0 = __umul24(row, ld8) + c8[0];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) v[i] = p[coff[i]];
+                for (int i = 0; i < NT - 1; ++i) v[i] = *(const double*)(ub + (size_t)r0 + 128 * i);
+                v[NT - 1] = *(const double*)(ub + (size_t)(__umul24(row, ld8) + c8[NT - 1]));
+            } else {
+                const unsigned ro = __umul24(row, ld8);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) v[i] = *(const double*)(ub + (size_t)(ro + c8[i]));
+            }
+        } else {
+            const double* p = src.base + (long long)row_pref * src.ld;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) v[i] = p[coff[i]];
+        }
         sub = 0.0;
         if constexpr (!LEAN) {
             if (has_sub) sub = sub_pref;
@@ -368,6 +392,7 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
         hs.sub_row = nullptr;
         hs.count = A.hf_count ? A.hf_count[w] : A.m;
         hs.count0 = 0x7fffffff; hs.jump = 0;
+        hs.off32 = (A.hf_off32 & 1) != 0;
         // ---- phase A: the shift row of the one-pass centred scatter (see posterior_fused_impl.h) = the window's first row
         const bool ones = kc < 15;        // a spare column k+1 carries ones; otherwise the sums are kept by vector adds (wave_gram)
         double shift[NT], w0v[NT], csum[NT];
@@ -482,6 +507,7 @@ __device__ __forceinline__ void wave_window_body(const tp_kargs_t& A, double* ld
         ds.sub_row = A.rf_adj ? A.rf_adj + w * (long long)A.n_r : nullptr;
         ds.count = A.n_rows ? A.n_rows[w] : A.n_r;
         ds.count0 = 0x7fffffff; ds.jump = 0;
+        ds.off32 = (A.panel_off32 & 1) != 0;
         double none[NT] = {};
         bool shared = false;
         const double* q = nullptr;

@@ -122,6 +122,7 @@ namespace {
 std::mutex g_registry_mutex;
 std::vector<tp_handle_t> g_live_handles;
 std::atomic<bool> g_shut_down{false};
+std::atomic<bool> g_exiting{false};        // inside the exit handler: release resources, never start a collective
 bool g_atexit_registered = false;
 
 bool runtime_gone(hipError_t e) {
@@ -138,6 +139,7 @@ int destroy_handle(tp_handle_t h, bool device_calls);
 int destroy_batch(tp_batch_t b, bool device_calls);
 
 void shutdown_at_exit() {
+    g_exiting.store(true);
     std::vector<tp_handle_t> live;
     { std::lock_guard<std::mutex> lk(g_registry_mutex); live.swap(g_live_handles); }
     for (tp_handle_t h : live) (void)destroy_handle(h, true);
@@ -464,7 +466,8 @@ int destroy_batch(tp_batch_t b, bool device_calls) {
     if (device_calls) {
         // A gather that was requested (tp_batch_gather_async) but not yet put on its stream is a collective the peer
         // ranks may already be waiting in: issue it before the buffers go away - dropping it would hang them.
-        if (h->deferred == b) (void)flush_gather(h);
+        // (not at process exit: the peers may be gone, and a collective nobody answers would hang the exit)
+        if (h->deferred == b && !g_exiting.load()) (void)flush_gather(h);
         (void)hipStreamSynchronize(h->stream);      // (the lanes of the large-k path have joined the kernel stream)
         if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);   // a gather may still read the results
         for (hipEvent_t e : b->gather_done)
