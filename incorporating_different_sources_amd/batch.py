@@ -68,13 +68,11 @@ class MarketPanels:
         self.P = prices.to_numpy(dtype=np.float64)
         D, K = self.P.shape
         # length of the run of non-NaN prices ending at each row (ref:646 `.tail(n).notna().all()`)
+        # = row index minus the row of the last NaN at or above it (a running maximum down the columns: no Python loop)
         ok = ~np.isnan(self.P)
-        run = np.zeros((D, K), dtype=np.int32)
-        acc = np.zeros(K, dtype=np.int32)
-        for i in range(D):
-            acc = np.where(ok[i], acc + 1, 0)
-            run[i] = acc
-        self.valid_run = run
+        rows = np.arange(D, dtype=np.int32)[:, None]
+        last_nan = np.maximum.accumulate(np.where(ok, np.int32(-1), rows), axis=0) if D else np.zeros((0, K), np.int32)
+        self.valid_run = (rows - last_nan).astype(np.int32)
 
         caps = market_data["stock_market_caps_df"]
         self.caps_has = np.array([t in caps.columns for t in self.tickers])
