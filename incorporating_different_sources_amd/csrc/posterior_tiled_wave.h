@@ -303,8 +303,13 @@ __device__ __forceinline__ void tw_mfma_agpr_neg(d4& c, double a, double b) {
 // UPDATE: the block first takes its left-looking update A_jj -= sum_{q<j} R_qj' R_qj here (rows 0 .. 64 j - 1 of the arena,
 // columns of super-tile j: four operand loads and ten MFMAs per 4-row k-step, the tiles on and above the diagonal only)
 // instead of in a launch of its own (tile64_kernel<MODE_SYRK_DIAG>: 201 us per block step at k = 500, 8 % of the run).
+// waves per SIMD the register allocator is asked to keep.  Two (round 3, A/B build -DTP_DIAG_OCC=2: 128 + 128 registers, 51
+// spilled) measured 16.36-16.53 ms against 16.28-16.30 ms per 4,096 windows at k = 500 and +-0 at k = 1000: not adopted
+#ifndef TP_DIAG_OCC
+#define TP_DIAG_OCC 1
+#endif
 template <bool UPDATE>
-__global__ void __launch_bounds__(64, 1) tiled_diag_wave_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws, const int j) {
+__global__ void __launch_bounds__(64, TP_DIAG_OCC) tiled_diag_wave_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws, const int j) {
     constexpr int MLD = 17;
     __shared__ __attribute__((aligned(16))) double lds[256 + 256 + 16 * MLD];          // diagonal tile | identity | M_a
     double* DG = lds;
