@@ -93,6 +93,24 @@ def parse_args():
     return ap.parse_args()
 
 
+def cpu_quota_cores():
+    """CPU cores this job's cgroup may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown."""
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt and txt[0] != "max":
+            return float(txt[0]) / float(txt[1])
+    except (OSError, ValueError, IndexError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p > 0:
+            return q / p
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def visible_gpus_sysfs():
     """GPUs the KFD topology lists, read from sysfs: the launcher must not initialise HIP (its workers do)."""
     n = 0
@@ -437,7 +455,9 @@ def worker(args):
             "launch": launch,
             "device": info["name"].strip() or "AMD Instinct MI355X",
             "h2d_ms": h2d_ms, "d2h_ms": d2h_ms, "gather_ms": tim["gather_ms"] if gather_mode == "rccl" else None,
-            "host": {"cpus": len(os.sched_getaffinity(0))},
+            "host": {"cpus": len(os.sched_getaffinity(0)), "cpu_quota_cores": cpu_quota_cores(),
+                     "note": "a one-GPU box of this pool shares its host: the affinity mask shows every hardware thread, the "
+                             "cgroup quota (when set) is what this job may actually use - the all-core CPU leg oversubscribes it"},
         }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
