@@ -34,7 +34,7 @@ CLOCK_HZ = 2.4e9               # nominal shader clock the peak is quoted at
 N_SIMD = 1024                  # 256 CUs x 4 SIMDs
 FLOPS_PER_MFMA_F64 = 2048      # v_mfma_f64_16x16x4_f64: 16 x 16 x 4 multiply-adds
 WINDOWS_PER_RANK = {4: 25_000, 5: 125_000}     # configs[3] / configs[4]: 200k resp. 1M windows over 8 GPUs
-HF_PANEL_BUDGET_BYTES = 24e9   # host bytes of the synthetic intraday panel per rank above which it wraps (hf_period)
+HF_PANEL_BUDGET_BYTES = 24e9   # host bytes of the synthetic intraday panels of ALL ranks above which they wrap (hf_period)
 # the unmodified reference, one window per call, measured in the survey container (8 cores)
 REFERENCE_AS_SHIPPED = {100: {"windows_per_s": 29.0, "check_off_windows_per_s": 74.0},
                         10: {"windows_per_s": 52.0, "check_off_windows_per_s": 84.0},
@@ -207,8 +207,9 @@ def worker(args):
     hf_period = args.hf_period
     if hf_period < 0:
         full_bytes = (W + shp["hf_days"] - 1) * synthetic.BARS_PER_DAY * k * 8.0
-        hf_period = 0 if (full_bytes <= HF_PANEL_BUDGET_BYTES or not conj) else \
-            max(1, int(HF_PANEL_BUDGET_BYTES / (synthetic.BARS_PER_DAY * k * 8.0)) - shp["hf_days"])
+        budget = HF_PANEL_BUDGET_BYTES / cp.world            # the ranks of a node share its host memory
+        hf_period = 0 if (full_bytes <= budget or not conj) else \
+            max(1, int(budget / (synthetic.BARS_PER_DAY * k * 8.0)) - shp["hf_days"])
     inp = synthetic.make_kernel_inputs(k, N, W, seed=shp["seed"] + 1000 * cp.rank, hf_days=shp["hf_days"],
                                        hf_period=hf_period)
 
