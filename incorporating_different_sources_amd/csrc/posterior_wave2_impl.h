@@ -17,7 +17,9 @@
 //     16-pivot chain and publishes M = R_jj^-T; every wave turns its tiles of the block row into R_jJ = M A_jJ with
 //     the tile's own registers as the B operand and stores them - register r of a tile is rows 4r..4r+3 in MFMA operand
 //     layout, so the LDS image is a plain lane-linear dump - and the trailing update A_IJ -= R_jI' R_jJ reads the A
-//     operands it does not own from that image.  Two workgroup barriers per block step, none elsewhere in the phase;
+//     operands it does not own from that image.  NO workgroup barrier inside the factorisation: the waves meet through
+//     flags in LDS, and the owner of the next diagonal tile runs its pivot chain while the others finish the trailing
+//     update (data-flow form, phase F below; one instantiation keeps a barrier pair per block step, w2_dataflow);
 //   * the back substitution runs along block rows: lane-local products over a wave's own tiles, one 16-lane DPP
 //     reduction per register, the NWV partial vectors meet in LDS (one barrier per block row, double-buffered) and every
 //     wave forms w_I = M' z for itself.
