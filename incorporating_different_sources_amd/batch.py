@@ -106,6 +106,17 @@ class MarketPanels:
         self.L_nan = np.ones(self.base.shape, dtype=bool)      # return row i: base row i-1 -> base row i
         if len(self.base) > 1:
             self.L_nan[1:] = _return_is_nan(self.base[1:], self.base[:-1])
+        # Running counts, so that "is any return of rows a..b of these columns NaN" is O(k) per date instead of a
+        # gather of the whole window (the gathers were half of pack_windows' time): per column for the daily / binned
+        # returns, over all columns for the (much longer) intraday panel.
+        self.L_nan_cum = np.concatenate([np.zeros((1, K), np.int32), np.cumsum(self.L_nan, axis=0, dtype=np.int32)])
+        self.H_rownan_cum = np.concatenate([[0], np.cumsum(self.H_nan.any(axis=1), dtype=np.int64)])
+        # whole days between consecutive labels (`.dt.days` of the label differences, ref:40) and the risk-free value
+        # each label takes by forward fill (ref:54), once per panel
+        self.label_gap_days = np.diff(self.label_ns) // _NS_PER_DAY
+        ridx = np.searchsorted(self.rf_ns, self.label_ns, side="right") - 1
+        self.rf_at_label = np.where(ridx >= 0, self.rf[np.maximum(ridx, 0)], np.nan) if len(self.rf) else np.full(len(self.label_ns), np.nan)
+        self.ticker_arr = np.array(self.tickers, dtype=object)
         self._mcm = {}
         self.weights_cache = {}        # (spec key, dates) -> device results, filled by cross-spec batches
 
@@ -151,8 +162,8 @@ def clear_panel_cache():
     _PANEL_CACHE.clear()
 
 
-def _mean_gap_and_check(label_ns):
-    gaps = np.diff(label_ns) // _NS_PER_DAY                    # `.dt.days` of the label differences (ref:40)
+def _mean_gap_and_check(gaps):
+    """`gaps`: whole days between consecutive labels of the window (MarketPanels.label_gap_days slice)."""
     mean_gap = gaps.mean()
     assert gaps.max() <= mean_gap + 4, "Unexpected large gap between return dates."
     return mean_gap
@@ -194,7 +205,6 @@ def pack_universes(trading_dates, portfolio_spec, market_data, members_of=None):
     W, K = len(trading_dates), len(mp.tickers)
     col_idx = np.zeros((W, k), dtype=np.int32)
     caps_all = np.zeros((W, k), dtype=np.float64)
-    labels = []
     all_members = np.ones(K, dtype=bool)
     for w, ts in enumerate(trading_dates):
         pos, members = _date_position_and_members(mp, ts, members_of, all_members)
@@ -202,12 +212,11 @@ def pack_universes(trading_dates, portfolio_spec, market_data, members_of=None):
         if len(cols) != k:
             raise ValueError(f"universe has {len(cols)} assets, portfolio_spec['size'] is {k}")
         col_idx[w], caps_all[w] = cols, caps
-        labels.append([mp.tickers[c] for c in cols])
         lo_row = max(0, pos + 1 - window_days)                     # ref:986-988
-        if np.isnan(mp.P[lo_row:pos + 1][:, cols]).any():
+        if (mp.valid_run[pos, cols] < pos + 1 - lo_row).any():
             logger.error("Found NA values in the filtered stock prices.")
             raise ValueError("The filtered stock prices contain NA values.")
-    return col_idx, labels, caps_all
+    return col_idx, mp.ticker_arr[col_idx].tolist(), caps_all
 
 
 def _date_position_and_members(mp, ts, members_of, all_members):
@@ -263,7 +272,6 @@ def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None, re
 
     col_idx = np.zeros((W, k), dtype=np.int32)
     caps_all = np.zeros((W, k), dtype=np.float64)
-    labels = []
     row_idx = np.zeros((W, n_r_max), dtype=np.int32)
     n_rows = np.zeros(W, dtype=np.int32)
     rf_adj = np.zeros((W, n_r_max), dtype=np.float64)
@@ -283,10 +291,10 @@ def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None, re
             raise ValueError(f"universe has {len(cols)} assets, portfolio_spec['size'] is {k}")
         col_idx[w] = cols
         caps_all[w] = caps
-        labels.append([mp.tickers[c] for c in cols])
-        # ref:986-988: the filtered prices of the window must be complete
+        # ref:986-988: the filtered prices of the window must be complete (the run of non-NaN prices that ends at
+        # the date covers the window: O(k), not a gather of the window)
         lo_row = max(0, pos + 1 - window_days)
-        if np.isnan(mp.P[lo_row:pos + 1][:, cols]).any():
+        if (mp.valid_run[pos, cols] < pos + 1 - lo_row).any():
             logger.error("Found NA values in the filtered stock prices.")
             raise ValueError("The filtered stock prices contain NA values.")
 
@@ -294,7 +302,7 @@ def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None, re
         if freq == "daily":
             first_price = max(0, pos - N + 1)
             rows = np.arange(first_price + 1, pos + 1, dtype=np.int64)        # returns of prices first_price..pos
-            lab = mp.date_ns[first_price:pos + 1]
+            lab0, lab1 = first_price, pos                                      # labels lab0..lab1 of mp.label_ns
         else:
             b = int(mp.bin_of[pos])
             first_bin = max(0, b - N + 1)
@@ -305,17 +313,19 @@ def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None, re
             if tail_nan is not None:
                 tails.append((pos, b - 1))
                 rows = np.concatenate([body, [base_rows + len(tails) - 1]])
-            lab = mp.label_ns[first_bin:b + 1]
-        if len(lab) >= 2:
-            mean_gap = _mean_gap_and_check(lab)
-            ridx = np.searchsorted(mp.rf_ns, lab[1:], side="right") - 1        # ffill on labels (ref:54)
-            rfv = np.where(ridx >= 0, mp.rf[np.maximum(ridx, 0)], np.nan)
+            lab0, lab1 = first_bin, b
+        if lab1 > lab0:
+            mean_gap = _mean_gap_and_check(mp.label_gap_days[lab0:lab1])
+            rfv = mp.rf_at_label[lab0 + 1:lab1 + 1]                            # ffill on labels (ref:54)
             adj = (1 + rfv) ** (mean_gap / 365) - 1                            # ref:48
         else:
             raise AssertionError("Unexpected large gap between return dates.")
         # dropna (ref:60): a NaN risk-free value or a NaN return of a selected asset drops the row
         if freq == "daily":
-            vals_nan = mp.L_nan[rows][:, cols].any(axis=1)
+            if len(rows) and (mp.L_nan_cum[pos + 1, cols] != mp.L_nan_cum[first_price + 1, cols]).any():
+                vals_nan = mp.L_nan[rows][:, cols].any(axis=1)
+            else:
+                vals_nan = np.zeros(len(rows), dtype=bool)
         else:
             block = mp.L_nan[body][:, cols]
             if tail_nan is not None:
@@ -335,7 +345,7 @@ def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None, re
             end_of_day = pd.Timestamp(ts).replace(hour=23, minute=59, second=59).value
             e = int(np.searchsorted(mp.hf_ns, min(d + _NS_PER_DAY, end_of_day), side="right"))
             cand = np.arange(a + 1, e, dtype=np.int64)                          # the first bar's return is NaN (shift)
-            if len(cand):
+            if len(cand) and mp.H_rownan_cum[e] != mp.H_rownan_cum[a + 1]:   # some bar of the span has a NaN somewhere
                 cand = cand[~mp.H_nan[cand][:, cols].any(axis=1)]
             hf_rows.append(cand)
             hf_count[w] = len(cand)
@@ -346,6 +356,7 @@ def pack_windows(trading_dates, portfolio_spec, market_data, members_of=None, re
                 w0[w] = 1 / k                                                   # ref:670-672
             n0[w] = _prior_strength(mp, mcm, d, ts, N, portfolio_spec["mcm_scaling"])
 
+    labels = mp.ticker_arr[col_idx].tolist()
     if (n_rows < 1).any():
         raise ValueError("a rolling window has no usable return rows")
     # Price panel + the (numerator, denominator) rows of every return row; the device takes the logarithms.
