@@ -929,11 +929,13 @@ hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStre
         int np = 0;
         for (int i = 0; i < NS; ++i) np += (NS - i + 1) / 2;
         hipLaunchKernelGGL(tiled_gram_wave_pair_kernel, xcd_grid(np, G), dim3(64), 0, stream, a, ws, np);
-    } else if (use_wave)
+    } else if (use_wave && !conj)             // Jeffreys: the rank-one term J = T - t t'/N inside the Gram kernel
+        hipLaunchKernelGGL(tiled_gram_wave_rank1_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(64), 0, stream, a, ws);
+    else if (use_wave)
         hipLaunchKernelGGL(tiled_gram_wave_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(64), 0, stream, a, ws);
     else if (lean) hipLaunchKernelGGL(tiled_gram_lean_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws);
     else hipLaunchKernelGGL(tile64_kernel<MODE_GRAM>, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws, 0);
-    if (!conj) hipLaunchKernelGGL(tiled_rank1_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws);
+    if (!conj && !(use_wave && a.opts.tiled_wave != 2)) hipLaunchKernelGGL(tiled_rank1_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(NTHREADS), 0, stream, a, ws);
     hipLaunchKernelGGL(tiled_clear_kernel, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
     // Left-looking blocked Cholesky: block row j first receives the updates of ALL earlier block rows in one
     // pass (every arena tile is read and written once per factorisation, not once per block step), then its

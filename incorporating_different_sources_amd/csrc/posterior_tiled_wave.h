@@ -36,10 +36,12 @@ __device__ __forceinline__ void tw_settle8(d4& c0, d4& c1, d4& c2, d4& c3, d4& c
 //  !HF: daily rows minus the risk-free adjustment, border column 1 (ref:57, 180, 222)
 //  NB: 16-column B groups per k-step: 4 = one 64 x 64 super-tile, 8 = two super-tiles side by side (64 x 128, the pair
 //  kernel: the A operands are loaded once for both)
-template <bool DIAG, bool EDGE, bool HF, int NB>
+//  CS: also keep the column sums of the staged values (this lane's rows only) in cs[] - the Jeffreys rank-one term fused
+//  into the Gram kernel needs t = X'1 for the rows AND the columns of the super-tile (gram64_wave_body, RANK1)
+template <bool DIAG, bool EDGE, bool HF, int NB, bool CS = false>
 __device__ __forceinline__ void tw_gram_pass(const TRows& src, const long long (&co)[4 + NB], const double (&yb)[4 + NB],
                                              const bool (&cval)[4 + NB], const bool (&cbord)[4 + NB], const double sqs, const int lane,
-                                             d4 (&acc)[4 * NB]) {
+                                             d4 (&acc)[4 * NB], double (&cs)[4 + NB]) {
     constexpr int NO = DIAG ? NB : 4 + NB;      // operand registers per k-step (a diagonal super-tile: its B groups are the A groups)
     const int fq = lane >> 4;
     const int nks = (src.count + 3) >> 2;
@@ -77,6 +79,10 @@ __device__ __forceinline__ void tw_gram_pass(const TRows& src, const long long (
             const bool rv = 4 * ks + fq < src.count;
 #pragma unroll
             for (int i = 0; i < NO; ++i) v[i] = rv ? v[i] : 0.0;
+        }
+        if constexpr (CS) {
+#pragma unroll
+            for (int i = 0; i < NO; ++i) cs[i] += v[i];
         }
         static_for_t<0, 4>([&](auto ac) __attribute__((always_inline)) {
             constexpr int a = decltype(ac)::value;
@@ -118,9 +124,15 @@ __device__ __forceinline__ void tw_gram_pass(const TRows& src, const long long (
 
 // PAIR: the wave owns super-tiles (SI, SJ) AND (SI, SJ + 1): 32 tiles = all 256 AGPRs, one wave per SIMD, 12 operand loads
 // and 32 MFMAs per k-step (a diagonal pair: 8 loads, 26 MFMAs) instead of 2 x (8 loads, 16 MFMAs)
-template <bool DIAG, bool EDGE, bool PAIR = false>
+// RANK1 (Jeffreys, 64 x 64 form): J = T - t t'/N (+ the optional shift d I + e 1 1') applied to the super-tile while it is
+// still in registers, instead of by tiled_rank1_kernel's read-modify-write pass over the whole arena (34 % of a Jeffreys
+// run at k = 500: 9.1 ms per 8,192 windows, its column of t read with a 4 KB stride).  t for the rows of SI and the columns
+// of SJ: the border column of the shared table slots of super-tiles (SI, NS-1) and (SJ, NS-1) (four lanes hold it) plus
+// the column sums of the rows this wave stages itself, put together in 1 KB of LDS.
+template <bool DIAG, bool EDGE, bool PAIR = false, bool RANK1 = false>
 __device__ __forceinline__ void gram64_wave_body(const tp_kargs_t& A, const tp_tiled_ws_t& ws, const long long wl, const int SI,
-                                                 const int SJ) {
+                                                 const int SJ, double* tv_lds = nullptr) {
+    static_assert(!(PAIR && RANK1), "the fused rank-one term is built for the 64 x 64 form");
     constexpr int NB = PAIR ? 8 : 4;
     constexpr int NC = 4 + NB;
     const int lane = threadIdx.x;
@@ -156,14 +168,19 @@ __device__ __forceinline__ void gram64_wave_body(const tp_kargs_t& A, const tp_t
         tw_pin1(acc[decltype(tc)::value]);
     });
 
-    if (conj) {
-        TRows hs;
-        hs.base = A.hf_panel; hs.ld = A.hf_ld;
-        hs.ridx = A.hf_row_idx ? A.hf_row_idx + w * (long long)A.m : nullptr;
-        hs.first = A.hf_start ? A.hf_start[w] : 0;
-        hs.rowc = ws.zc + wl * (long long)A.m;
-        hs.count = mm; hs.count0 = 0x7fffffff; hs.jump = 0;
-        tw_gram_pass<DIAG, EDGE, true, NB>(hs, co, yb, cval, cbord, sqs, lane, acc);
+    double cs[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) cs[i] = 0.0;
+    if constexpr (!RANK1) {
+        if (conj) {
+            TRows hs;
+            hs.base = A.hf_panel; hs.ld = A.hf_ld;
+            hs.ridx = A.hf_row_idx ? A.hf_row_idx + w * (long long)A.m : nullptr;
+            hs.first = A.hf_start ? A.hf_start[w] : 0;
+            hs.rowc = ws.zc + wl * (long long)A.m;
+            hs.count = mm; hs.count0 = 0x7fffffff; hs.jump = 0;
+            tw_gram_pass<DIAG, EDGE, true, NB>(hs, co, yb, cval, cbord, sqs, lane, acc, cs);
+        }
     }
     // daily rows; with the shared block-window sums only the rows in front of the first whole aligned block and behind
     // the last one (see gram64_lean_body)
@@ -182,11 +199,66 @@ __device__ __forceinline__ void gram64_wave_body(const tp_kargs_t& A, const tp_t
         ds.jump = (int)(CH * pb1 - ds.first) - ds.count0;
         ds.count = ds.count0 + (int)(ds.first + nr - CH * pb1);
     }
-    tw_gram_pass<DIAG, EDGE, false, NB>(ds, co, yb, cval, cbord, sqs, lane, acc);
+    tw_gram_pass<DIAG, EDGE, false, NB, RANK1>(ds, co, yb, cval, cbord, sqs, lane, acc, cs);
 
     // the table slot (tile row a of the super-tile at a time) and the store to the arena
     typedef double d2 __attribute__((ext_vector_type(2)));
     const long long ntile = (long long)ws.NS * (ws.NS + 1) / 2;
+    // ---- RANK1: t for the 64 rows of SI (tv[0..63]) and the 64 columns of SJ (tv[64..127])
+    double invN = 0.0, sh_d = 0.0, sh_e = 0.0;
+    if constexpr (RANK1) {
+        invN = A.center_rows == 2 ? 0.0 : 1.0 / (double)(A.center_rows ? nr : A.N);
+        sh_d = A.shift ? A.shift[2 * w] : 0.0;
+        sh_e = A.shift ? A.shift[2 * w + 1] : 0.0;
+        // column sums of the rows staged here: add up the four row groups of a k-step (lanes 16 apart)
+#pragma unroll
+        for (int i = 0; i < (DIAG ? NB : NC); ++i) {
+            double x = cs[i];
+            x += __shfl_xor(x, 16);
+            x += __shfl_xor(x, 32);
+            cs[i] = x;
+        }
+        if (fq == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                tv_lds[16 * i + fr] = cs[i];
+                tv_lds[64 + 16 * i + fr] = cs[DIAG ? i : 4 + i];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (shared) {
+            // border column k of the table: super-tile column NS - 1, 16-column group bk, lane column kc; the lanes fr == kc
+            // hold rows fq + 4 r of tile row a in the registers of the slot
+            const int kl = k - 64 * (ws.NS - 1), bk = kl >> 4, kc = kl & 15;
+            if (fr == kc) {
+#pragma unroll
+                for (int side = 0; side < (DIAG ? 1 : 2); ++side) {
+                    const int S = side == 0 ? SI : SJ;
+                    const d2* qb = (const d2*)(A.winsum + (((long long)li * A.prefix_nblk + pb0) * ntile + pair_index(S, ws.NS - 1, ws.NS)) * (SB * SB)) + lane;
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const d2 lo = qb[a * 512 + (bk * 2 + 0) * 64], hi = qb[a * 512 + (bk * 2 + 1) * 64];
+                        // rows of super-tile S that are assets only (the border row itself is never used as t)
+                        tv_lds[64 * side + 16 * a + fq + 0] += lo[0];
+                        tv_lds[64 * side + 16 * a + fq + 4] += lo[1];
+                        tv_lds[64 * side + 16 * a + fq + 8] += hi[0];
+                        tv_lds[64 * side + 16 * a + fq + 12] += hi[1];
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (DIAG && lane < 64) tv_lds[64 + lane] = tv_lds[lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    double tj[NB];
+    if constexpr (RANK1) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) tj[b] = tv_lds[64 + 16 * b + fr];
+    }
     // (the super-tiles of a pair are neighbours in the row-major numbering of the triangle: slot of (SI, SJ + 1) = slot + 1)
     const d2* q = shared ? (const d2*)(A.winsum + (((long long)li * A.prefix_nblk + pb0) * ntile + pair_index(SI, SJ, ws.NS)) * (SB * SB)) + lane
                          : nullptr;
@@ -207,6 +279,17 @@ __device__ __forceinline__ void gram64_wave_body(const tp_kargs_t& A, const tp_t
                 x[0] += v2[b][0][0]; x[1] += v2[b][0][1];
                 x[2] += v2[b][1][0]; x[3] += v2[b][1][1];
             }
+            if constexpr (RANK1) {
+                if (!DIAG || a <= b) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int gi = 64 * SI + 16 * a + fq + 4 * r, gj = 64 * SJ + 16 * b + fr;
+                        const double ti = tv_lds[16 * a + fq + 4 * r];
+                        const double add = sh_e + (gi == gj ? sh_d : 0.0) - invN * (ti * tj[b]);
+                        x[r] += (!EDGE || (gi < k && gj < k)) ? add : 0.0;
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) M[(long long)(64 * SI + 16 * a + fq + 4 * r) * KP + 64 * SJ + 16 * b + fr] = x[r];
         });
@@ -226,6 +309,23 @@ __global__ void __launch_bounds__(64, 2) tiled_gram_wave_kernel(const tp_kargs_t
     } else {
         if (edge) gram64_wave_body<false, true>(A, ws, wl, SI, SJ);
         else gram64_wave_body<false, false>(A, ws, wl, SI, SJ);
+    }
+}
+
+// Jeffreys with the rank-one term fused (no tiled_rank1_kernel behind it)
+__global__ void __launch_bounds__(64, 2) tiled_gram_wave_rank1_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws) {
+    long long wl;
+    int tile, SI, SJ;
+    if (!xcd_window_tile(ws.NS * (ws.NS + 1) / 2, A.w_count, wl, tile)) return;
+    pair_decode(tile, ws.NS, SI, SJ);
+    const bool edge = !(64 * SJ + 63 < A.k);
+    __shared__ double tv[128];
+    if (SI == SJ) {
+        if (edge) gram64_wave_body<true, true, false, true>(A, ws, wl, SI, SJ, tv);
+        else gram64_wave_body<true, false, false, true>(A, ws, wl, SI, SJ, tv);
+    } else {
+        if (edge) gram64_wave_body<false, true, false, true>(A, ws, wl, SI, SJ, tv);
+        else gram64_wave_body<false, false, false, true>(A, ws, wl, SI, SJ, tv);
     }
 }
 

@@ -397,7 +397,10 @@ def test_layouts_are_bitwise_equivalent(native, k, N, hf_days):
 @pytest.mark.parametrize("k,N,hf_days,strat,W", [(7, 600, 1, "conjugate", 40), (100, 250, 1, "conjugate", 300),
                                                  (130, 700, 2, "jeffreys", 50), (200, 1200, 3, "conjugate", 20),
                                                  (240, 300, 2, "conjugate", 40), (300, 700, 1, "jeffreys", 30),
-                                                 (500, 250, 5, "conjugate", 48), (1000, 500, 22, "conjugate", 20)])
+                                                 (500, 250, 5, "conjugate", 48), (1000, 500, 22, "conjugate", 20),
+                                                 # Jeffreys on the tiled path: the rank-one term is fused into the Gram kernel
+                                                 # (border column at the last / the first column of its super-tile)
+                                                 (447, 900, 1, "jeffreys", 12), (512, 1100, 1, "jeffreys", 12)])
 def test_shared_gram_prefixes(native, k, N, hf_days, strat, W):
     """Rolling windows over one panel (register-tile path and tiled path; windows that span several restarts of the running sums): the whole aligned 16-row blocks of every window come from the
     shared running sums (W n_r >= 3 panel rows switches them on) - against the oracle at the flat 1e-10 bound, against

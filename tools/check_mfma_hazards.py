@@ -9,7 +9,7 @@ their destination AGPRs.  This script proves its absence on the generated ISA:
 
     hipcc -O3 ... -S --cuda-device-only posterior_wave_nt.hip -o wave.s ;  check_mfma_hazards.py wave.s
 
-For every kernel whose name contains `posterior_wave_kernel`, `posterior_wave2_kernel` or `tiled_gram_wave_kernel` it walks the instruction stream (following branches
+For every kernel whose name contains `posterior_wave_kernel`, `posterior_wave2_kernel` or `tiled_gram_wave*_kernel` it walks the instruction stream (following branches
 for as long as a result is pending) and reports any instruction that reads or writes a register of an asm MFMA's
 destination less than 19 wait states after that MFMA, other than an MFMA accumulating into exactly that tile.
 Exit code 1 on a finding.  Run by tests/test_cabi_symbols.py::test_wave_kernel_asm_hazards (CPU, cross-compile).
@@ -132,7 +132,7 @@ def main(path):
     text = open(path).read().split("\n")
     kernels, cur = {}, None
     for ln in text:
-        m = re.match(r"^(_Z\w*(?:posterior_wave_kernel|posterior_wave2_kernel|tiled_gram_wave_kernel|tiled_gram_wave_pair_kernel|tiled_diag_wave_kernel)\w*):", ln)
+        m = re.match(r"^(_Z\w*(?:posterior_wave_kernel|posterior_wave2_kernel|tiled_gram_wave_kernel|tiled_gram_wave_rank1_kernel|tiled_gram_wave_pair_kernel|tiled_diag_wave_kernel)\w*):", ln)
         if m:
             cur = kernels.setdefault(m.group(1), [])
             continue
