@@ -408,6 +408,9 @@ __device__ __forceinline__ void tw_mfma_agpr_neg(d4& c, double a, double b) {
 #ifndef TP_DIAG_OCC
 #define TP_DIAG_OCC 1
 #endif
+#ifndef TP_DIAG_DEPTH
+#define TP_DIAG_DEPTH 8
+#endif
 template <bool UPDATE>
 __global__ void __launch_bounds__(64, TP_DIAG_OCC) tiled_diag_wave_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws, const int j) {
     constexpr int MLD = 17;
@@ -464,23 +467,23 @@ __global__ void __launch_bounds__(64, TP_DIAG_OCC) tiled_diag_wave_kernel(const 
                 });
             });
         };
-        double va[4], vb[4], vc[4];
-        load(va, 0);
-        load(vb, 1);
+        // TP_DIAG_DEPTH k-steps of operand loads in flight (nks = 16 j is a multiple of it: no remainder code).  Eight
+        // against the three of round 2 measured +-0 (k = 500, 8,192 windows: 31.7 / 18.3 ms conjugate / Jeffreys either
+        // way): the kernel is bound by its serial work (ten MFMAs per k-step, then 64 pivots), not by the latency of
+        // the arena rows.
+        constexpr int D = TP_DIAG_DEPTH;
+        static_assert(16 % D == 0, "the update loop runs whole groups of D k-steps");
+        double v[D][4];
+        static_for_t<0, D>([&](auto dc) __attribute__((always_inline)) { load(v[decltype(dc)::value], decltype(dc)::value); });
         static_for_t<0, 10>([&](auto tc) __attribute__((always_inline)) { tw_pin1(acc[decltype(tc)::value]); });
-        int ks = 0;
 #pragma nounroll
-        for (; ks + 3 <= nks; ks += 3) {                   // nks = 16 j >= 16: whole triples, then one or two k-steps
-            load(vc, ks + 2 < nks ? ks + 2 : nks - 1);
-            step(va);
-            load(va, ks + 3 < nks ? ks + 3 : nks - 1);
-            step(vb);
-            load(vb, ks + 4 < nks ? ks + 4 : nks - 1);
-            step(vc);
-        }
-        if (ks < nks) {
-            step(va);
-            if (ks + 1 < nks) step(vb);
+        for (int ks = 0; ks < nks; ks += D) {
+            static_for_t<0, D>([&](auto dc) __attribute__((always_inline)) {
+                constexpr int d = decltype(dc)::value;
+                step(v[d]);
+                const int nx = ks + D + d;
+                load(v[d], nx < nks ? nx : nks - 1);       // (past the end: a re-read of the last k-step, never used)
+            });
         }
         tw_settle8(acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
         tw_settle2(acc[8], acc[9]);
