@@ -276,3 +276,53 @@ def test_two_wave_kernel_layouts_shared_sums_and_singular_windows(native, k, N):
     sing = synthetic.make_kernel_inputs(k, 60, 5, seed=1)
     _, s, _ = native.posterior_batch("jeffreys", k, 60, 5.0, panel=sing["panel"], start=sing["start"], n_r=sing["n_r"])
     assert (s != 0).all()
+
+
+@pytest.mark.parametrize("k,N", [(260, 520), (383, 700), (448, 800)])
+def test_tiled_jeffreys_rank_one_term_in_every_layout(native, k, N):
+    """Large-k path, Jeffreys: J = T - t t'/N is applied inside the Gram kernel (posterior_tiled_wave.h, RANK1) from the
+    border column of the shared table slots and the column sums of the rows a wave stages itself.  The border column sits
+    in the first / the last / a middle 16-column group of its super-tile; contiguous windows with the shared sums, without
+    them, ragged windows with a risk-free adjustment, gathered columns and explicit rows - against the oracle at 1e-10 and
+    against the 4-wave kernels (separate rank-one pass, option tiled_wave = 0)."""
+    rng = np.random.default_rng(k)
+    W = 14
+    width = k + 7
+    inp = synthetic.make_kernel_inputs(width, N, W, seed=4100 + k)
+    n_r = inp["n_r"]
+    dense = np.ascontiguousarray(inp["panel"][:, :k])
+    assert W * n_r >= 3 * dense.shape[0]
+    kw = dict(panel=dense, start=inp["start"], n_r=n_r)
+    w_sh, s_sh, _ = native.posterior_batch("jeffreys", k, N, 5.0, **kw)
+    w_no, s_no, _ = native.posterior_batch("jeffreys", k, N, 5.0, flags=native.FLAG_NO_SHARED_GRAM, **kw)
+    ref, rstat, _ = oracle.posterior_batch_c("jeffreys", k, N, 5.0, **kw)
+    assert (s_sh == rstat).all() and (s_no == rstat).all() and (rstat == 0).all()
+    np.testing.assert_allclose(w_sh, ref, **WTOL)
+    np.testing.assert_allclose(w_no, ref, **WTOL)
+    dev = native.default_device()
+    dev.set_option("tiled_wave", 0)
+    try:
+        w_4w, s_4w, _ = native.posterior_batch("jeffreys", k, N, 5.0, **kw)
+    finally:
+        dev.set_option("tiled_wave", -1)
+    np.testing.assert_allclose(w_sh, w_4w, rtol=0, atol=1e-11 * max(1.0, np.abs(w_4w).max()))
+    # general layout: gathered columns, explicit ragged rows, per-row risk-free adjustment, a shift on some windows
+    cols = np.stack([np.sort(rng.choice(width, k, replace=False)) for _ in range(W)]).astype(np.int32)
+    rows = np.stack([inp["start"][w] + np.sort(rng.choice(n_r, n_r, replace=False)) for w in range(W)]).astype(np.int32)
+    gkw = dict(panel=inp["panel"], start=None, row_idx=rows, col_idx=cols, n_r=n_r,
+               n_rows=rng.integers(n_r - 9, n_r + 1, W).astype(np.int32), rf_adj=rng.normal(1e-4, 3e-5, size=(W, n_r)))
+    refg, rstatg, _ = oracle.posterior_batch_c("jeffreys", k, N, 5.0, **gkw)
+    wg, sg, _ = native.posterior_batch("jeffreys", k, N, 5.0, **gkw)
+    assert (sg == rstatg).all() and (rstatg == 0).all()
+    np.testing.assert_allclose(wg, refg, **WTOL)
+    # contiguous windows with ragged row counts and an adjustment (no sharing: rf_adj), and with the shift d I + e 1 1'
+    ckw = dict(panel=dense, start=inp["start"], n_r=n_r, n_rows=gkw["n_rows"], rf_adj=gkw["rf_adj"])
+    refc, _, _ = oracle.posterior_batch_c("jeffreys", k, N, 5.0, **ckw)
+    wc, sc, _ = native.posterior_batch("jeffreys", k, N, 5.0, **ckw)
+    assert (sc == 0).all()
+    np.testing.assert_allclose(wc, refc, **WTOL)
+    shift = np.column_stack([rng.gamma(1.0, 5.0, W), rng.uniform(0, 20.0, W)])
+    refs, _, _ = oracle.posterior_batch("jeffreys", k, N, 5.0, **kw, shift=shift)
+    ws, ss, _ = native.posterior_batch("jeffreys", k, N, 5.0, **kw, shift=shift)
+    assert (ss == 0).all()
+    np.testing.assert_allclose(ws, refs, rtol=0, atol=1e-10 * max(1.0, np.abs(refs).max()))
