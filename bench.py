@@ -329,7 +329,7 @@ def worker(args):
             oracle.posterior_batch_c(args.strategy, k, N, 5.0, threads=threads, **oracle_kw(min(sample, 2 * threads)))
             reps, cdt = 0, 0.0
             c0 = time.perf_counter()
-            while cdt < budget_s and reps < 20:
+            while cdt < budget_s and reps < 400:
                 oracle.posterior_batch_c(args.strategy, k, N, 5.0, threads=threads, **oracle_kw(sample))
                 reps += 1
                 cdt = time.perf_counter() - c0
@@ -339,9 +339,9 @@ def worker(args):
         # all host cores and one core; the 16-thread leg is this pool's per-GPU CPU share
         per_thread = max(8, int(2.5e9 / alg_flops_per_window(k, n_r, m, conj)))      # ~1 s of one core
         all_cores = max(1, min(oracle.c_num_threads(), len(os.sched_getaffinity(0))))
-        cpu = time_cpu(all_cores, min(W, per_thread * all_cores), 2.0)
-        cpu16 = time_cpu(min(16, all_cores), min(W, per_thread * min(16, all_cores)), 1.5) if all_cores > 16 else cpu
-        cpu1 = time_cpu(1, min(W, per_thread), 1.5)
+        cpu = time_cpu(all_cores, min(W, per_thread * all_cores), 6.0)        # ~16 s of CPU work in the three legs
+        cpu16 = time_cpu(min(16, all_cores), min(W, per_thread * min(16, all_cores)), 6.0) if all_cores > 16 else cpu
+        cpu1 = time_cpu(1, min(W, per_thread), 4.0)
         shipped = REFERENCE_AS_SHIPPED.get(k)
         cpu["reference_as_shipped"] = None if shipped is None or not conj else dict(
             shipped, cores=8, unit="windows/s", source="BASELINE.md section 2: the unmodified reference "
