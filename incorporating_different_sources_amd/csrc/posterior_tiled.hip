@@ -778,6 +778,12 @@ void tp_tiled_geometry(int k, int* KP, int* NS, int* NSB) {
 // rate (9.5 % of the run).  Runs after tiled_diag*_kernel(j), which needs the updated tile (j, j) first (its own launch).
 // Staging as in tile64_kernel; in the TRSM part the B half of chunk c (rows 16c..16c+15 of the tile) comes from the
 // accumulators of wave c instead of from memory.
+// chunks of operand loads in flight in the left-looking update.  2 (A/B build -DTP_SYRK_DEPTH=2, round 3: 136 instead of
+// 112 registers, three instead of four workgroups per CU) measured 32.0 / 18.4 ms against 31.7 / 18.3 ms per 8,192 windows
+// at k = 500 (conjugate / Jeffreys): the kernel is bound by HBM bytes (4.6 TB/s read + written), not by their latency
+#ifndef TP_SYRK_DEPTH
+#define TP_SYRK_DEPTH 1
+#endif
 __global__ void __launch_bounds__(NTHREADS) tile64_syrk_trsm_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws, const int j) {
     __shared__ __attribute__((aligned(16))) double lds[2 * CH * LDX];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -801,25 +807,18 @@ __global__ void __launch_bounds__(NTHREADS) tile64_syrk_trsm_kernel(const tp_kar
     double v[8];
     // ---- left-looking update: rows of block rows 0 .. j-1, A half = columns of super-tile j, B half = columns of super-tile J
     const int nchunks = (SB / CH) * j;
-    auto load = [&](int ch) __attribute__((always_inline)) {
+    auto load = [&](double (&vv)[8], int ch) __attribute__((always_inline)) {
         const double* row = M + (long long)(ch * CH + srow) * KP;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = row[64 * SI + cb + 16 * i];
+        for (int i = 0; i < 4; ++i) vv[i] = row[64 * SI + cb + 16 * i];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[4 + i] = row[64 * SJ + cb + 16 * i];
+        for (int i = 0; i < 4; ++i) vv[4 + i] = row[64 * SJ + cb + 16 * i];
     };
-    auto store = [&](double* buf) __attribute__((always_inline)) {
+    auto store = [&](double* buf, const double (&vv)[8]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) buf[srow * LDX + 64 * (i >> 2) + cb + 16 * (i & 3)] = v[i];
+        for (int i = 0; i < 8; ++i) buf[srow * LDX + 64 * (i >> 2) + cb + 16 * (i & 3)] = vv[i];
     };
-    if (nchunks > 0) { load(0); store(lds); }
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        double* cur = lds + (ch & 1) * CH * LDX;
-        double* nxt = lds + ((ch + 1) & 1) * CH * LDX;
-        const bool more = ch + 1 < nchunks;
-        if (more) load(ch + 1);
-        __builtin_amdgcn_sched_barrier(0);
+    auto mma = [&](const double* cur) __attribute__((always_inline)) {
         const double* lb = cur + fq * LDX + fr;
 #pragma unroll
         for (int s4 = 0; s4 < CH / 4; ++s4) {
@@ -828,9 +827,40 @@ __global__ void __launch_bounds__(NTHREADS) tile64_syrk_trsm_kernel(const tp_kar
             for (int b = 0; b < 4; ++b)
                 acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, lb[4 * s4 * LDX + 64 + 16 * b], acc[b], 0, 0, 1);
         }
-        if (more) store(nxt);
+    };
+    double* buf0 = lds;
+    double* buf1 = lds + CH * LDX;
+#if TP_SYRK_DEPTH == 2
+    double v2[8];
+    if (nchunks > 0) { load(v, 0); store(buf0, v); }
+    if (nchunks > 1) load(v, 1);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ch += 2) {             // nchunks = 4 j: even
+        if (ch + 2 < nchunks) load(v2, ch + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(buf0);
+        store(buf1, v);                                    // chunk ch + 1
+        __syncthreads();
+        if (ch + 3 < nchunks) load(v, ch + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(buf1);
+        if (ch + 2 < nchunks) store(buf0, v2);
         __syncthreads();
     }
+#else
+    if (nchunks > 0) { load(v, 0); store(buf0, v); }
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        double* cur = lds + (ch & 1) * CH * LDX;
+        double* nxt = lds + ((ch + 1) & 1) * CH * LDX;
+        const bool more = ch + 1 < nchunks;
+        if (more) load(v, ch + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(cur);
+        if (more) store(nxt, v);
+        __syncthreads();
+    }
+#endif
     // ---- R_jJ = R_jj^-T A_jJ: chunk c = rows 16c..16c+15 of R_jj^-1 (A half, from memory) and of the tile (B half, wave c's registers)
     d4 res[4];
 #pragma unroll
