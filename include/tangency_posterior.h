@@ -140,6 +140,9 @@ int tp_destroy(tp_handle_t h);
  *   "no_shared_gram"   1 = as if every batch carried TP_FLAG_NO_SHARED_GRAM (takes effect at the next upload)
  *   "tiled_arena_gib" / "tiled_arena_mib"  in-flight arena of the large-k path, per lane (0: default)
  *   "tiled_lanes"      sub-batches of the large-k path in flight at once, each on a stream of its own (0 / 1: one)
+ *   "hf_share_min_blocks"  large-k path, conjugate: intraday windows that advance by a fixed stride share the Grams of
+ *                      their whole stride-long blocks from this many whole blocks per window on (default 6; takes effect
+ *                      at the next upload; "no_shared_gram" switches the scheme off)
  * Replaces nothing in the reference. */
 int tp_set_option(tp_handle_t h, const char* name, int value);
 const char* tp_last_error(tp_handle_t h); /* h may be NULL: last error of a failed tp_create */

@@ -55,6 +55,13 @@ struct tp_kargs_t {
     // L that occurs among the batch's windows (at most TP_WINSUM_MAX_L)
     const double* winsum; // Q tables: [n_L][prefix_nblk][slot]
     int winsum_L[4];      // the block counts L (0 = unused entry)
+    // large-k path, conjugate, contiguous intraday windows that advance by a fixed stride B (one day of bars): the whole
+    // B-row blocks of every window come from block Grams of the intraday panel that the windows of ONE sub-batch share
+    // (DESIGN.md section 4b).  Tables of the sub-batch in flight, rebuilt by every launch; null = every row through the MFMAs
+    const double* hf_prefix;   // block Grams [hf_nblk][slot] of the raw intraday rows (ones in the border column)
+    const double* hf_winsum;   // block-window sums [hf_nblk][slot]: Q[b] = G[b] + .. + G[b + hf_L - 1]
+    long long hf_row0;         // intraday panel row where block 0 of these tables starts
+    int hf_blk_rows, hf_nblk, hf_L;
     const double* rhs;    // optional [W x k]: replaces the border column before the factorisation
     const double* shift;  // optional [W x 2], Jeffreys only: (d, e) adds d I + e 1 1' to the matrix that is factorised
     double* weights;
@@ -120,6 +127,7 @@ struct tp_tiled_ws_t {
     double* zc;
     double* scal;
     int* flags;
+    double* part;         // shared intraday sums: partial products S w0 per (window, row block, column block) [G][NS][NS][64]
     int KP, NS, NSB;
 };
 int tp_tiled_max_assets(void);

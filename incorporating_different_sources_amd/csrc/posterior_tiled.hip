@@ -754,6 +754,39 @@ __global__ void __launch_bounds__(NTHREADS) tiled_clear_kernel(const tp_kargs_t 
     const long long wl = blockIdx.x;
     const int k = A.k, KP = ws.KP;
     double* M = ws.arena + wl * (long long)KP * KP;
+    if (A.strategy == 0 && A.hf_winsum != nullptr) {
+        // shared intraday sums (posterior_tiled_wave.h): S0 w0 from the super-tiles' pieces in a fixed order, then
+        // q0 = w0' S0 w0, c (ref:415-418) and c S0 w0 into the border column, where the two-pass form's Gram puts it
+        __shared__ double red[4];
+        const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+        const long long w = A.w_first + wl;
+        const int NS = ws.NS;
+        const double* part = ws.part + (wl * NS * NS) * 64;
+        double* v0 = ws.ybar + wl * KP;
+        double qq = 0.0;
+        for (int i = tid; i < k; i += NTHREADS) {
+            const double* pp = part + ((long long)(i >> 6) * NS) * 64 + (i & 63);
+            double v = 0.0;
+            for (int src = 0; src < NS; ++src) v += pp[src * 64];
+            v0[i] = v;
+            qq = fma(A.w0[w * k + i], v, qq);
+        }
+        qq = wave_sum64(qq);
+        if (lane == 0) red[wv] = qq;
+        __syncthreads();
+        const double q0 = ((red[0] + red[1]) + red[2]) + red[3];
+        const double n0 = A.n0[w];
+        const double mm = (double)A.m;
+        const double s = n0 * (mm / (mm - 1.0));
+        const double a = n0 + k + 2;
+        const double c = (2 * n0) / (a + sqrt(a * a + 4 * n0 * q0));
+        for (int i = tid; i < k; i += NTHREADS) M[(long long)i * KP + k] += c * v0[i];
+        if (tid == 0) {
+            double* o = ws.scal + wl * 8;
+            o[0] = s; o[1] = sqrt(s); o[2] = c; o[3] = q0; o[4] = n0;
+        }
+        __syncthreads();
+    }
     for (int e = threadIdx.x; e < (KP - k) * KP; e += NTHREADS) M[(long long)k * KP + e] = 0.0;
     if (A.rhs != nullptr)     // caller-supplied right-hand side in place of the border column
         for (int i = threadIdx.x; i < k; i += NTHREADS) M[(long long)i * KP + k] = A.rhs[(A.w_first + wl) * k + i];
@@ -936,7 +969,8 @@ hipError_t tp_tiled_prefix_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, 
                                  stream);
 }
 
-hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStream_t stream, bool build_prefix) {
+hipError_t tp_tiled_launch(const tp_kargs_t& a_in, const tp_tiled_ws_t& ws, hipStream_t stream, bool build_prefix) {
+    tp_kargs_t a = a_in;
     const int G = (int)a.w_count;
     if (G <= 0) return hipSuccess;
     const int NS = ws.NS, NSB = ws.NSB;
@@ -947,15 +981,27 @@ hipError_t tp_tiled_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, hipStre
         hipError_t e = tp_tiled_prefix_launch(a, ws, stream);
         if (e != hipSuccess) return e;
     }
-    if (conj) {
+    // one wavefront per super-tile (posterior_tiled_wave.h) unless TP_TILED_WAVE=0 asks for the 4-wave kernels (A/B runs)
+    const bool use_wave = a.opts.tiled_wave != 0;
+    // shared intraday sums of this sub-batch (tangency_api.cpp plans them; the default one-wave kernels only)
+    const bool hfs = conj && a_in.hf_winsum != nullptr && use_wave && a_in.opts.tiled_wave != 2;
+    if (!hfs) a.hf_winsum = nullptr;
+    if (hfs) {
+        const long long ntile = (long long)NS * (NS + 1) / 2;
+        hipLaunchKernelGGL(tiled_hf_block_gram_kernel, dim3((unsigned)(a.hf_nblk * ntile)), dim3(64), 0, stream, a, ws, (double*)a.hf_prefix);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        e = tp_window_sums_launch(a.hf_prefix, (double*)a.hf_winsum, a.hf_nblk, tp_tiled_slot_doubles(a.k), &a.hf_L, 1, stream);
+        if (e != hipSuccess) return e;
+    } else if (conj) {
         const int nci = (a.k + 63) / 64;
         if (nci <= 8) hipLaunchKernelGGL(tiled_prior_kernel<8>, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
         else if (nci <= 16) hipLaunchKernelGGL(tiled_prior_kernel<16>, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
         else hipLaunchKernelGGL(tiled_prior_kernel<32>, dim3(G), dim3(NTHREADS), 0, stream, a, ws);
     }
-    // one wavefront per super-tile (posterior_tiled_wave.h) unless TP_TILED_WAVE=0 asks for the 4-wave kernels (A/B runs)
-    const bool use_wave = a.opts.tiled_wave != 0;
-    if (a.opts.tiled_wave == 2) {             // 64 x 128 per wavefront (A/B: option tiled_wave = 2)
+    if (hfs)
+        hipLaunchKernelGGL(tiled_gram_wave_hfs_kernel, xcd_grid(NS * (NS + 1) / 2, G), dim3(64), 0, stream, a, ws);
+    else if (a.opts.tiled_wave == 2) {        // 64 x 128 per wavefront (A/B: option tiled_wave = 2)
         int np = 0;
         for (int i = 0; i < NS; ++i) np += (NS - i + 1) / 2;
         hipLaunchKernelGGL(tiled_gram_wave_pair_kernel, xcd_grid(np, G), dim3(64), 0, stream, a, ws, np);

@@ -312,6 +312,312 @@ __global__ void __launch_bounds__(64, 2) tiled_gram_wave_kernel(const tp_kargs_t
     }
 }
 
+// ---- shared intraday sums (conjugate, large-k path) ------------------------------------------------------------------
+// The intraday windows of consecutive dates overlap by all but one day: 388 of 389 rows at configs[2], 1,637 of 1,715 at
+// configs[4], and pushing them through the MFMAs for every window was 52 % / 67 % of those runs.  Here the raw rows of each
+// B-row block (one day of bars) are multiplied ONCE per sub-batch (tiled_hf_block_gram_kernel), tp_window_sums_kernel adds L
+// consecutive block Grams up (additions only, as for the daily panel), and a window takes
+//     S0 = s [ Q[b0] + (its rows outside whole blocks)' (same) - t t'/m ],      t = column sums of its rows
+// with t from the border (ones) column of Q and the column sums of the edge rows - the centring the two-pass form gets from
+// (y - ybar) becomes a rank-one term in registers.  What the two-pass form fed through the border column, c sqrt(s) z_r with
+// z_r = (y_r - ybar).w0, is c S0 w0: every super-tile writes its 64-row pieces of S0 w0 (rows of I from the columns of J,
+// and for I < J rows of J from the columns of I) to ws.part, and tiled_clear_kernel adds them up in a fixed order, forms
+// q0 = w0' S0 w0 and c (ref:415-418) and puts c S0 w0 into the border column.  No tiled_prior_kernel, no pass over the
+// intraday rows per window at all.
+template <bool DIAG, bool EDGE>
+__device__ __forceinline__ void hfblock64_wave_body(const tp_kargs_t& A, const tp_tiled_ws_t& ws, double* out, const long long blk,
+                                                    const long long tile, const int SI, const int SJ) {
+    constexpr int NB = 4, NC = 8;
+    const int lane = threadIdx.x;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int k = A.k;
+    long long co[NC];
+    double yb[NC], cs[NC];
+    bool cval[NC], cbord[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int st = DIAG ? SI + (i >> 2) : (i < 4 ? SI : SJ + ((i - 4) >> 2));
+        const int gc = 64 * st + fr + 16 * (i & 3);
+        cval[i] = !EDGE || gc < k;
+        cbord[i] = EDGE && gc == k;                                 // ones: the border column of a block Gram is its column sums
+        co[i] = cval[i] ? gc : k - 1;
+        yb[i] = 0.0; cs[i] = 0.0;
+    }
+    d4 acc[4 * NB];
+    static_for_t<0, 4 * NB>([&](auto tc) __attribute__((always_inline)) {
+        acc[decltype(tc)::value] = d4{0.0, 0.0, 0.0, 0.0};
+        tw_pin1(acc[decltype(tc)::value]);
+    });
+    TRows hs;
+    hs.base = A.hf_panel; hs.ld = A.hf_ld; hs.ridx = nullptr; hs.rowc = nullptr;
+    hs.first = A.hf_row0 + blk * A.hf_blk_rows;
+    hs.count = A.hf_blk_rows; hs.count0 = 0x7fffffff; hs.jump = 0;
+    tw_gram_pass<DIAG, EDGE, false, NB>(hs, co, yb, cval, cbord, 0.0, lane, acc, cs);
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const long long ntile = (long long)ws.NS * (ws.NS + 1) / 2;
+    d2* p = (d2*)(out + (blk * ntile + tile) * (SB * SB)) + lane;
+    static_for_t<0, 4>([&](auto ac) __attribute__((always_inline)) {
+        constexpr int a = decltype(ac)::value;
+        static_for_t<0, NB>([&](auto bc) __attribute__((always_inline)) {
+            constexpr int b = decltype(bc)::value;
+            const d4 x = acc[NB * a + b];                           // (below the diagonal of a diagonal super-tile: zeros)
+            p[a * 512 + (b * 2 + 0) * 64] = d2{x[0], x[1]};
+            p[a * 512 + (b * 2 + 1) * 64] = d2{x[2], x[3]};
+        });
+    });
+}
+
+__global__ void __launch_bounds__(64, 2) tiled_hf_block_gram_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws, double* out) {
+    const long long ntile = (long long)ws.NS * (ws.NS + 1) / 2;
+    const long long blk = blockIdx.x / ntile;
+    const int tile = (int)(blockIdx.x % ntile);
+    int SI, SJ;
+    pair_decode(tile, ws.NS, SI, SJ);
+    const bool edge = !(64 * SJ + 63 < A.k);
+    if (SI == SJ) {
+        if (edge) hfblock64_wave_body<true, true>(A, ws, out, blk, tile, SI, SJ);
+        else hfblock64_wave_body<true, false>(A, ws, out, blk, tile, SI, SJ);
+    } else {
+        if (edge) hfblock64_wave_body<false, true>(A, ws, out, blk, tile, SI, SJ);
+        else hfblock64_wave_body<false, false>(A, ws, out, blk, tile, SI, SJ);
+    }
+}
+
+// t (column sums over a window's rows) for the 64 rows of SI -> tv[0..63] and the 64 columns of SJ -> tv[64..127]: the column
+// sums `cs` of the rows this wave staged (this lane's row group only, on entry) plus - when `tab` - the border column of the
+// table slots whose row blocks are SI and SJ (qI / qJ: slot of super-tile (S, NS-1), already offset by the lane)
+template <bool DIAG>
+__device__ __forceinline__ void tw_build_t(double (&cs)[8], double* tv, const bool tab, const double* qI, const double* qJ,
+                                           const int k, const int NS, const int lane) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < (DIAG ? 4 : 8); ++i) {
+        double x = cs[i];
+        x += __shfl_xor(x, 16);
+        x += __shfl_xor(x, 32);
+        cs[i] = x;
+    }
+    if (fq == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            tv[16 * i + fr] = cs[i];
+            tv[64 + 16 * i + fr] = cs[DIAG ? i : 4 + i];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (tab) {
+        // border column k of the table: super-tile column NS - 1, 16-column group bk, lane column kc; the lanes fr == kc
+        // hold rows fq + 4 r of tile row a in the registers of the slot
+        const int kl = k - 64 * (NS - 1), bk = kl >> 4, kc = kl & 15;
+        if (fr == kc) {
+#pragma unroll
+            for (int side = 0; side < (DIAG ? 1 : 2); ++side) {
+                const d2* qb = (const d2*)(side == 0 ? qI : qJ);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const d2 lo = qb[a * 512 + (bk * 2 + 0) * 64], hi = qb[a * 512 + (bk * 2 + 1) * 64];
+                    tv[64 * side + 16 * a + fq + 0] += lo[0];
+                    tv[64 * side + 16 * a + fq + 4] += lo[1];
+                    tv[64 * side + 16 * a + fq + 8] += hi[0];
+                    tv[64 * side + 16 * a + fq + 12] += hi[1];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (DIAG) tv[64 + lane] = tv[lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// One super-tile of a conjugate window with the shared intraday sums.  lds: tv[128] | pI[64] | pJ[64]
+template <bool DIAG, bool EDGE>
+__device__ __forceinline__ void gram64_wave_hfs_body(const tp_kargs_t& A, const tp_tiled_ws_t& ws, const long long wl, const int SI,
+                                                     const int SJ, double* lds) {
+    constexpr int NB = 4, NC = 8;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    double* tv = lds;
+    double* pI = lds + 128;
+    double* pJ = lds + 192;
+    const int lane = threadIdx.x;
+    const int fr = lane & 15, fq = lane >> 4;
+    const long long w = A.w_first + wl;
+    const int k = A.k, KP = ws.KP, NS = ws.NS;
+    double* M = ws.arena + wl * (long long)KP * KP;
+    const int mm = A.m;                                             // uniform intraday row count (host-checked)
+    const int nr = A.n_rows ? A.n_rows[w] : A.n_r;
+    const long long ntile = (long long)NS * (NS + 1) / 2;
+    long long co[NC];
+    double yb[NC], cs[NC];
+    bool cval[NC], cbord[NC], cnone[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int st = DIAG ? SI + (i >> 2) : (i < 4 ? SI : SJ + ((i - 4) >> 2));
+        const int gc = 64 * st + fr + 16 * (i & 3);
+        cval[i] = !EDGE || gc < k;
+        cbord[i] = EDGE && gc == k;
+        cnone[i] = false;
+        co[i] = cval[i] ? gc : k - 1;
+        yb[i] = 0.0; cs[i] = 0.0;
+    }
+    pI[lane] = 0.0;
+    pJ[lane] = 0.0;
+    d4 acc[4 * NB];
+    static_for_t<0, 4 * NB>([&](auto tc) __attribute__((always_inline)) {
+        acc[decltype(tc)::value] = d4{0.0, 0.0, 0.0, 0.0};
+        tw_pin1(acc[decltype(tc)::value]);
+    });
+    // ---- intraday: the rows outside the whole blocks, raw (no border column: the column sums are kept in cs)
+    const long long hfirst = A.hf_start[w];
+    const long long Bk = A.hf_blk_rows;
+    const long long hb0 = (hfirst - A.hf_row0 + Bk - 1) / Bk, hb1 = (hfirst + mm - A.hf_row0) / Bk;
+    {
+        TRows hs;
+        hs.base = A.hf_panel; hs.ld = A.hf_ld; hs.ridx = nullptr; hs.rowc = nullptr;
+        hs.first = hfirst;
+        hs.count0 = (int)(A.hf_row0 + Bk * hb0 - hfirst);
+        hs.jump = (int)(Bk * (hb1 - hb0));
+        hs.count = hs.count0 + (int)(hfirst + mm - (A.hf_row0 + Bk * hb1));
+        tw_gram_pass<DIAG, EDGE, false, NB, true>(hs, co, yb, cval, cnone, 0.0, lane, acc, cs);
+    }
+    const double* hq = A.hf_winsum + (hb0 * ntile) * (SB * SB);
+    tw_build_t<DIAG>(cs, tv, true, hq + pair_index(SI, NS - 1, NS) * (SB * SB) + 2 * lane, hq + pair_index(SJ, NS - 1, NS) * (SB * SB) + 2 * lane,
+                     k, NS, lane);
+    // ---- S0 = s (Q + edge - t t'/m) in registers, and this super-tile's pieces of S0 w0
+    {
+        const double n0 = A.n0[w];
+        const double sc = n0 * ((double)mm / ((double)mm - 1.0));
+        const double minv = 1.0 / (double)mm;
+        const double* w0 = A.w0 + w * k;
+        double tj[NB], w0j[NB], colp[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int gj = 64 * SJ + 16 * b + fr;
+            tj[b] = tv[64 + 16 * b + fr];
+            w0j[b] = (!EDGE || gj < k) ? w0[gj < k ? gj : k - 1] : 0.0;
+            colp[b] = 0.0;
+        }
+        const d2* q = (const d2*)(hq + pair_index(SI, SJ, NS) * (SB * SB)) + lane;
+        static_for_t<0, 4>([&](auto ac) __attribute__((always_inline)) {
+            constexpr int a = decltype(ac)::value;
+            d2 v2[NB][2];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) v2[b][h] = q[a * 512 + (b * 2 + h) * 64];
+            double ti[4], w0i[4], rowp[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = 64 * SI + 16 * a + fq + 4 * r;              // (SI <= SJ: rows of SI are assets unless SI is the last block)
+                ti[r] = tv[16 * a + fq + 4 * r];
+                w0i[r] = (gi < k) ? w0[gi] : 0.0;
+                rowp[r] = 0.0;
+            }
+            static_for_t<0, NB>([&](auto bc) __attribute__((always_inline)) {
+                constexpr int b = decltype(bc)::value;
+                if constexpr (!DIAG || a <= b) {
+                    d4 x = acc[NB * a + b];
+                    x[0] += v2[b][0][0]; x[1] += v2[b][0][1];
+                    x[2] += v2[b][1][0]; x[3] += v2[b][1][1];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int gi = 64 * SI + 16 * a + fq + 4 * r, gj = 64 * SJ + 16 * b + fr;
+                        double y = sc * fma(-minv * ti[r], tj[b], x[r]);
+                        y = (gi < k && gj < k) ? y : 0.0;
+                        x[r] = y;
+                        rowp[r] = fma(y, w0j[b], rowp[r]);
+                        if (!DIAG || a < b) colp[b] = fma(y, w0i[r], colp[b]);
+                    }
+                    acc[NB * a + b] = x;
+                    tw_pin1(acc[NB * a + b]);
+                }
+            });
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double sum = rowgroup_sum16(rowp[r]);
+                if (fr == 0) pI[16 * a + fq + 4 * r] = sum;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            double x = colp[b];
+            x += __shfl_xor(x, 16);
+            x += __shfl_xor(x, 32);
+            if (fq == 0) {
+                if (DIAG) pI[16 * b + fr] += x;                     // the mirrored halves of a diagonal super-tile: same rows
+                else pJ[16 * b + fr] = x;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        double* part = ws.part + (wl * NS * NS) * 64;
+        part[((long long)SI * NS + SJ) * 64 + lane] = pI[lane];
+        if (!DIAG) part[((long long)SJ * NS + SI) * 64 + lane] = pJ[lane];
+    }
+    // ---- daily rows on top (as in gram64_wave_body)
+    TRows ds;
+    ds.base = A.panel; ds.ld = A.panel_ld;
+    ds.ridx = nullptr;
+    ds.first = A.start[w];
+    ds.rowc = nullptr;
+    ds.count = nr; ds.count0 = 0x7fffffff; ds.jump = 0;
+    const long long pb0 = (ds.first + CH - 1) / CH, pb1 = (ds.first + nr) / CH;
+    const int Lw = (int)(pb1 - pb0);
+    const int li = Lw == A.winsum_L[0] ? 0 : Lw == A.winsum_L[1] ? 1 : Lw == A.winsum_L[2] ? 2 : Lw == A.winsum_L[3] ? 3 : -1;
+    const bool shared = A.winsum != nullptr && Lw > 0 && li >= 0;
+    if (shared) {
+        ds.count0 = (int)(CH * pb0 - ds.first);
+        ds.jump = (int)(CH * pb1 - ds.first) - ds.count0;
+        ds.count = ds.count0 + (int)(ds.first + nr - CH * pb1);
+    }
+    tw_gram_pass<DIAG, EDGE, false, NB>(ds, co, yb, cval, cbord, 0.0, lane, acc, cs);
+    const d2* q = shared ? (const d2*)(A.winsum + (((long long)li * A.prefix_nblk + pb0) * ntile + pair_index(SI, SJ, NS)) * (SB * SB)) + lane
+                         : nullptr;
+    static_for_t<0, 4>([&](auto ac) __attribute__((always_inline)) {
+        constexpr int a = decltype(ac)::value;
+        d2 v2[NB][2];
+        if (shared) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) v2[b][h] = q[a * 512 + (b * 2 + h) * 64];
+        }
+        static_for_t<0, NB>([&](auto bc) __attribute__((always_inline)) {
+            constexpr int b = decltype(bc)::value;
+            d4 x = acc[NB * a + b];
+            if (shared && (!DIAG || a <= b)) {
+                x[0] += v2[b][0][0]; x[1] += v2[b][0][1];
+                x[2] += v2[b][1][0]; x[3] += v2[b][1][1];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) M[(long long)(64 * SI + 16 * a + fq + 4 * r) * KP + 64 * SJ + 16 * b + fr] = x[r];
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+__global__ void __launch_bounds__(64, 2) tiled_gram_wave_hfs_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws) {
+    long long wl;
+    int tile, SI, SJ;
+    if (!xcd_window_tile(ws.NS * (ws.NS + 1) / 2, A.w_count, wl, tile)) return;
+    pair_decode(tile, ws.NS, SI, SJ);
+    const bool edge = !(64 * SJ + 63 < A.k);
+    __shared__ double lds[256];
+    if (SI == SJ) {
+        if (edge) gram64_wave_hfs_body<true, true>(A, ws, wl, SI, SJ, lds);
+        else gram64_wave_hfs_body<true, false>(A, ws, wl, SI, SJ, lds);
+    } else {
+        if (edge) gram64_wave_hfs_body<false, true>(A, ws, wl, SI, SJ, lds);
+        else gram64_wave_hfs_body<false, false>(A, ws, wl, SI, SJ, lds);
+    }
+}
+
 // Jeffreys with the rank-one term fused (no tiled_rank1_kernel behind it)
 __global__ void __launch_bounds__(64, 2) tiled_gram_wave_rank1_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws) {
     long long wl;

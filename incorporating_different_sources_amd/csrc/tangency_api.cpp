@@ -54,6 +54,7 @@ struct tp_handle_s {
     // one-process-all-GPUs mode while a test may be changing it).
     tp_kopts_t opts{};
     int no_shared_gram = 0;         // TP_NO_SHARED_GRAM / "no_shared_gram"
+    int hf_share_min_blocks = 6;    // "hf_share_min_blocks": whole intraday blocks per window from which the large-k path shares them
     int tiled_arena_gib = 0;        // TP_TILED_ARENA_GIB / "tiled_arena_gib" (0: default)
     int tiled_arena_mib = 0;        // TP_TILED_ARENA_MIB / "tiled_arena_mib": a sub-GiB arena per lane (depth-first sub-batches)
     int tiled_lanes = 0;            // TP_TILED_LANES / "tiled_lanes": sub-batches in flight on streams of their own (0: default)
@@ -89,6 +90,13 @@ struct tp_batch_s {
     int winsum_L[4] = {0, 0, 0, 0};                           // register-tile path: the whole-block counts of the windows
     DevBuf t_arena[TP_MAX_LANES], t_rinv[TP_MAX_LANES], t_ybar[TP_MAX_LANES], t_zc[TP_MAX_LANES], t_scal[TP_MAX_LANES],
         t_flags[TP_MAX_LANES];                                // large-k path workspace, one per lane
+    // large-k path, conjugate: shared intraday sums (posterior_tiled_wave.h).  Decided at upload (plan_shared_hf): the
+    // windows' intraday rows are contiguous, of one length, and advance by hf_B rows; the tables are per sub-batch
+    std::vector<int64_t> h_hf_start;                          // host copy of hf_start (the sub-batches' block ranges)
+    int hf_B = 0, hf_L = 0;                                   // rows per block (0 = not shared), whole blocks per window
+    long long hf_phase = 0;                                   // blocks start at rows = hf_phase (mod hf_B)
+    DevBuf hf_prefix;                                         // block Grams + block-window sums of the sub-batch in flight
+    DevBuf t_part[TP_MAX_LANES];                              // pieces of S0 w0 per (window, row block, column block)
     int64_t tiled_capacity = 0;                               // windows in flight per sub-batch (per lane)
     int tiled_lanes = 0;                                      // lanes the workspace was sized for
     bool uploaded = false;
@@ -383,12 +391,58 @@ int ensure_tiled_ws(tp_batch_t b, tp_tiled_ws_t* ws, int* lanes_out) {
         b->tiled_capacity = G;
         b->tiled_lanes = lanes;
     }
+    if (b->hf_B > 0)
+        for (int l = 0; l < lanes; ++l) {
+            int rc = ensure(h, b->t_part[l], sizeof(double) * (size_t)b->tiled_capacity * NS * NS * 64);
+            if (rc != TP_OK) return rc;
+        }
     for (int l = 0; l < lanes; ++l) {
         ws[l].arena = (double*)b->t_arena[l].p; ws[l].rinv = (double*)b->t_rinv[l].p; ws[l].ybar = (double*)b->t_ybar[l].p;
         ws[l].zc = (double*)b->t_zc[l].p; ws[l].scal = (double*)b->t_scal[l].p; ws[l].flags = (int*)b->t_flags[l].p;
+        ws[l].part = (double*)b->t_part[l].p;
         ws[l].KP = KP; ws[l].NS = NS; ws[l].NSB = NSB;
     }
     *lanes_out = lanes;
+    return TP_OK;
+}
+
+// Shared intraday sums of ONE sub-batch (windows sub.w_first .. + sub.w_count): the block range its windows cover, the
+// tables sized for it (block Grams, then the block-window sums).  A sub-batch whose windows do not all have hf_L whole blocks
+// inside one affordable range keeps the two-pass form (sub.hf_winsum stays null).
+int plan_hf_tables(tp_batch_t b, tp_kargs_t& sub) {
+    tp_handle_t h = b->h;
+    sub.hf_prefix = nullptr; sub.hf_winsum = nullptr;
+    const long long B = b->hf_B, ph = b->hf_phase, m = b->p.m;
+    long long lo = 0x7fffffffffffffffLL, hi = -1;
+    for (int64_t w = sub.w_first; w < sub.w_first + sub.w_count; ++w) {
+        const long long f = b->h_hf_start[(size_t)w];
+        const long long b0 = (f - ph + B - 1) / B, b1 = (f + m - ph) / B;      // f - ph > -B
+        if (b1 - b0 != b->hf_L) return TP_OK;
+        if (b0 < lo) lo = b0;
+        if (b1 > hi) hi = b1;
+    }
+    // the table starts on a multiple of the block-window sums' group length: a position's sum is then the same sequence of
+    // additions whichever sub-batch asks for it (results do not depend on how a run is cut into sub-batches)
+    const long long run = b->hf_L < TP_WINSUM_RUN ? b->hf_L : TP_WINSUM_RUN;
+    lo = (lo / run) * run;
+    const long long nblk = hi - lo;
+    if (nblk < b->hf_L || nblk > 0x3fffffff) return TP_OK;
+    // sharing pays while the windows outnumber the blocks they touch a few times over
+    if ((double)sub.w_count * (double)b->hf_L < 2.0 * (double)nblk) return TP_OK;
+    const size_t slot = tp_tiled_slot_doubles(b->p.k);
+    const size_t bytes = sizeof(double) * 2 * (size_t)nblk * slot;
+    if (bytes > b->hf_prefix.bytes) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > (free_b + b->hf_prefix.bytes) / 2) return TP_OK;
+        int rc = ensure(h, b->hf_prefix, bytes);
+        if (rc != TP_OK) return rc;
+    }
+    sub.hf_prefix = (const double*)b->hf_prefix.p;
+    sub.hf_winsum = (const double*)b->hf_prefix.p + (size_t)nblk * slot;
+    sub.hf_row0 = ph + B * lo;
+    sub.hf_blk_rows = (int)B;
+    sub.hf_nblk = (int)nblk;
+    sub.hf_L = b->hf_L;
     return TP_OK;
 }
 
@@ -438,6 +492,10 @@ int launch(tp_batch_t b, const tp_kargs_t& a, int64_t count, bool timed) {
         sub.w_first = a.w_first + w0;
         sub.w_count = (count - w0 < b->tiled_capacity) ? (count - w0) : b->tiled_capacity;
         const int l = (int)(sb % lanes);
+        if (b->hf_B > 0 && lanes == 1 && a.strategy == TP_STRATEGY_CONJUGATE) {
+            rc = plan_hf_tables(b, sub);
+            if (rc != TP_OK) return rc;
+        }
         hipError_t e = tp_tiled_launch(sub, ws[l], lanes > 1 ? h->lane_stream[l] : h->stream, lanes == 1 && w0 == 0);
         if (e != hipSuccess) return fail(h, TP_ERR_HIP, "tiled pipeline launch failed: %s", hipGetErrorString(e));
     }
@@ -479,10 +537,10 @@ int destroy_batch(tp_batch_t b, bool device_calls) {
                          &b->panel, &b->start, &b->row_idx, &b->n_rows, &b->col_idx, &b->rf_adj, &b->hf_panel, &b->hf_start,
                          &b->hf_row_idx, &b->hf_count, &b->w0, &b->n0, &b->weights, &b->status, &b->aux, &b->dbg,
                          &b->gather_w, &b->gather_s, &b->weights2, &b->status2, &b->stamps, &b->rhs, &b->out_rhs, &b->shift,
-                         &b->prefix};
+                         &b->prefix, &b->hf_prefix};
         for (DevBuf* d : all) release(*d);
         for (int l = 0; l < TP_MAX_LANES; ++l)
-            for (DevBuf* d : {&b->t_arena[l], &b->t_rinv[l], &b->t_ybar[l], &b->t_zc[l], &b->t_scal[l], &b->t_flags[l]}) release(*d);
+            for (DevBuf* d : {&b->t_arena[l], &b->t_rinv[l], &b->t_ybar[l], &b->t_zc[l], &b->t_scal[l], &b->t_flags[l], &b->t_part[l]}) release(*d);
     }
     if (h->deferred == b) h->deferred = nullptr;
     delete b;
@@ -590,6 +648,7 @@ int tp_set_option(tp_handle_t h, const char* name, int value) {
     else if (n == "tiled_arena_gib") h->tiled_arena_gib = value;
     else if (n == "tiled_arena_mib") h->tiled_arena_mib = value;
     else if (n == "tiled_lanes") h->tiled_lanes = value;
+    else if (n == "hf_share_min_blocks") h->hf_share_min_blocks = value;
     else return fail(h, TP_ERR_INVALID, "tp_set_option: unknown option '%s'", name);
     return TP_OK;
 }
@@ -717,6 +776,36 @@ static int plan_shared_gram(tp_batch_t b, const tp_inputs_t* in) {
     return TP_OK;
 }
 
+// Large-k path, conjugate: do the intraday windows qualify for shared sums (posterior_tiled_wave.h)?  Contiguous windows of
+// ONE length over ungathered columns, every start a fixed stride B after the previous one (rolling dates: one day of bars),
+// a contiguous daily layout without a risk-free adjustment (the kernel variant is built for that), and at least two whole
+// B-row blocks per window.  Blocks are aligned to the windows' ENDS: a window that starts behind a day's first bar
+// (its return is undefined, ref:311-312) ends on a day boundary.
+static void plan_shared_hf(tp_batch_t b, const tp_inputs_t* in) {
+    tp_handle_t h = b->h;
+    const tp_params_t& p = b->p;
+    b->hf_B = 0; b->hf_L = 0; b->hf_phase = 0;
+    b->h_hf_start.clear();
+    if (p.strategy != TP_STRATEGY_CONJUGATE || p.k <= tp_fused_max_assets()) return;
+    if ((p.flags & TP_FLAG_NO_SHARED_GRAM) || h->no_shared_gram) return;
+    if (!in->hf_start || in->hf_row_idx || in->hf_count || in->col_idx || in->row_idx || in->rf_adj || !in->start) return;
+    if (b->W < 4) return;
+    const long long B = in->hf_start[1] - in->hf_start[0];
+    if (B < 16 || B > 4096) return;
+    for (int64_t w = 1; w < b->W; ++w)
+        if (in->hf_start[w] - in->hf_start[w - 1] != B) return;
+    const long long m = p.m;
+    const long long ph = (in->hf_start[0] + m) % B;      // (start - ph > -B: the ceilings below stay exact)
+    const long long f = in->hf_start[0];
+    const long long L = (f + m - ph) / B - (f - ph + B - 1) / B;
+    // Measured at k = 500 (8,192 windows): with L = 4 whole days per window the tables cost what they save (block Grams 0.52 us +
+    // block-window sums 0.43 us + a second slot read per window against 312 rows at 4.6 ns); at k = 1,000 with L = 21:
+    // 21.1 k -> 49.3 k windows/s.  Break-even L = 3.5; shared from 6 (option hf_share_min_blocks, tests use 2).
+    if (L < 2 || L < h->hf_share_min_blocks) return;
+    b->hf_B = (int)B; b->hf_L = (int)L; b->hf_phase = ph;
+    b->h_hf_start.assign(in->hf_start, in->hf_start + b->W);
+}
+
 // H2D of one batch on stream `st`.  wait = true: the synchronous form (tp_batch_upload) on the kernel stream;
 // wait = false: copies are only queued (pinned host memory makes them truly asynchronous), upload_done marks their end.
 static int upload_common(tp_batch_t b, const tp_inputs_t* in, hipStream_t st, bool wait) {
@@ -780,6 +869,7 @@ static int upload_common(tp_batch_t b, const tp_inputs_t* in, hipStream_t st, bo
     b->hf_ld = conj ? in->hf_ld : 0;
     rc = plan_shared_gram(b, in);
     if (rc != TP_OK) return rc;
+    plan_shared_hf(b, in);
     HIP_TRY(h, hipEventRecord(e1, st));
     if (wait) {
         HIP_TRY(h, hipEventSynchronize(e1));

@@ -326,3 +326,55 @@ def test_tiled_jeffreys_rank_one_term_in_every_layout(native, k, N):
     ws, ss, _ = native.posterior_batch("jeffreys", k, N, 5.0, **kw, shift=shift)
     assert (ss == 0).all()
     np.testing.assert_allclose(ws, refs, rtol=0, atol=1e-10 * max(1.0, np.abs(refs).max()))
+
+
+@pytest.mark.parametrize("k,N,hf_days,W", [(260, 300, 3, 40), (383, 250, 5, 36), (500, 250, 5, 48), (1000, 500, 22, 40)])
+def test_shared_intraday_sums_on_the_large_k_path(native, k, N, hf_days, W):
+    """Conjugate windows whose intraday rows advance by one day per date: the whole days of every window come from block Grams
+    the windows of a sub-batch share (posterior_tiled_wave.h, tiled_gram_wave_hfs_kernel), the centring is a rank-one term
+    and c S0 w0 is assembled from the super-tiles' pieces.  Against the oracle (flat 1e-10, aux 1e-11), against the same
+    batch with every row through the MFMAs (TP_FLAG_NO_SHARED_GRAM), and bit-identical for a sub-batch."""
+    inp = synthetic.make_kernel_inputs(k, N, W, seed=5200 + k, hf_days=hf_days)
+    kw = dict(panel=inp["panel"], start=inp["start"], n_r=inp["n_r"], hf_panel=inp["hf_panel"], hf_start=inp["hf_start"],
+              m=inp["m"], w0=inp["w0"], n0=inp["n0"])
+    dev = native.default_device()
+    dev.set_option("hf_share_min_blocks", 2)                # (default 6: below that the tables cost what they save)
+    try:
+        wts, status, aux = native.posterior_batch("conjugate", k, N, 5.0, **kw)
+        part = {key: (val[W // 3:] if key in ("start", "hf_start", "w0", "n0") else val) for key, val in kw.items()}
+        wp, _, _ = native.posterior_batch("conjugate", k, N, 5.0, **part)
+    finally:
+        dev.set_option("hf_share_min_blocks", 6)
+    plain, pstat, paux = native.posterior_batch("conjugate", k, N, 5.0, flags=native.FLAG_NO_SHARED_GRAM, **kw)
+    assert (status == 0).all() and (pstat == 0).all()
+    np.testing.assert_allclose(wts, plain, rtol=0, atol=1e-12 * max(1.0, np.abs(plain).max()))
+    np.testing.assert_allclose(aux[:, :6], paux[:, :6], rtol=1e-11, atol=1e-14)
+    assert not np.array_equal(wts, plain)                   # (the two forms round differently: the shared path did run)
+    sel = np.array([0, 1, W // 2, W - 1])
+    sub = {key: (val[sel] if key in ("start", "hf_start", "w0", "n0") else val) for key, val in kw.items()}
+    ref, rstat, raux = oracle.posterior_batch_c("conjugate", k, N, 5.0, **sub)
+    np.testing.assert_allclose(wts[sel], ref, **WTOL)
+    np.testing.assert_allclose(aux[sel, :6], raux[:, :6], rtol=1e-11, atol=1e-14)
+    assert np.array_equal(wp, wts[W // 3:])
+
+
+def test_a_non_finite_intraday_row_poisons_only_the_windows_that_contain_it(native):
+    """Shared intraday sums are additions only: a NaN bar return makes the block Gram of ITS day NaN and with it the sums of
+    the windows that contain that day - the other windows come out bit-identical to the clean run."""
+    k, N, hf_days, W = 260, 300, 8, 30                      # 7 whole days per window: shared by default
+    inp = synthetic.make_kernel_inputs(k, N, W, seed=6100, hf_days=hf_days)
+    kw = dict(panel=inp["panel"], start=inp["start"], n_r=inp["n_r"], hf_panel=inp["hf_panel"], hf_start=inp["hf_start"],
+              m=inp["m"], w0=inp["w0"], n0=inp["n0"])
+    clean, cstat, _ = native.posterior_batch("conjugate", k, N, 5.0, **kw)
+    assert (cstat == 0).all()
+    plain, _, _ = native.posterior_batch("conjugate", k, N, 5.0, flags=native.FLAG_NO_SHARED_GRAM, **kw)
+    assert not np.array_equal(clean, plain)                 # the shared path ran
+    bad_row = 78 * 14 + 40
+    hf = inp["hf_panel"].copy()
+    hf[bad_row, 17] = np.nan
+    got, status, _ = native.posterior_batch("conjugate", k, N, 5.0, **dict(kw, hf_panel=hf))
+    inside = (inp["hf_start"] <= bad_row) & (bad_row < inp["hf_start"] + inp["m"])
+    assert inside.any() and (~inside).any()
+    assert (status[inside] != 0).all()
+    assert (status[~inside] == 0).all()
+    assert np.array_equal(got[~inside], clean[~inside])

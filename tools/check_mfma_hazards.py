@@ -132,7 +132,7 @@ def main(path):
     text = open(path).read().split("\n")
     kernels, cur = {}, None
     for ln in text:
-        m = re.match(r"^(_Z\w*(?:posterior_wave_kernel|posterior_wave2_kernel|tiled_gram_wave_kernel|tiled_gram_wave_rank1_kernel|tiled_gram_wave_pair_kernel|tiled_diag_wave_kernel)\w*):", ln)
+        m = re.match(r"^(_Z\w*(?:posterior_wave_kernel|posterior_wave2_kernel|tiled_gram_wave_kernel|tiled_gram_wave_rank1_kernel|tiled_gram_wave_hfs_kernel|tiled_hf_block_gram_kernel|tiled_gram_wave_pair_kernel|tiled_diag_wave_kernel)\w*):", ln)
         if m:
             cur = kernels.setdefault(m.group(1), [])
             continue
