@@ -252,6 +252,7 @@ def worker(args):
     batch = make_batch(args.layout)
     h2d_ms = dev.last_timing()["h2d_ms"]
     shared_blocks = batch.shared_gram_blocks()
+    shared_hf = batch.shared_intraday_blocks()
 
     def step():
         batch.run()
@@ -424,7 +425,7 @@ def worker(args):
                        "k": k, "N": N, "n_r": n_r, "m": m if conj else 0, "windows_per_gpu": W,
                        "strategy": args.strategy, "parallelism": f"windows sharded x{cp.world}",
                        "layout": args.layout, "hf_period_days": hf_period, "options": args.opt,
-                       "shared_gram_row_blocks": shared_blocks,
+                       "shared_gram_row_blocks": shared_blocks, "shared_intraday_blocks_per_window": shared_hf,
                        "gather": gather_mode, "rccl_ranks": rccl_ranks, "gather_verified": gathered_ok,
                        "rehearsal": rehearsal, "seed": shp["seed"]},
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -432,13 +433,15 @@ def worker(args):
                          # what `frac` is: SURVEY section 8(d)'s ALGORITHMIC flops (every window its own full Grams) over the
                          # measured time.  With shared Gram sums the kernels EXECUTE fewer flops than that, so this is an
                          # algorithmic-equivalent rate, not matrix-pipe utilisation - `executed` carries that
-                         "frac_kind": "algorithmic-equivalent (shared Gram sums: executed flops < algorithmic flops)"
-                                      if shared_blocks else "algorithmic flops; every row of every window goes through the MFMAs",
+                         "frac_kind": ("algorithmic-equivalent (shared Gram sums: executed flops < algorithmic flops"
+                                       + (f"; the intraday Grams too, {shared_hf} of a window's days from shared block Grams: this rate "
+                                          "can exceed the MFMA peak and is NOT a utilisation)" if shared_hf else ")"))
+                                      if (shared_blocks or shared_hf) else "algorithmic flops; every row of every window goes through the MFMAs",
                          "executed": executed_from_pmc(args.layout, k, W, args.strategy, kernel_ms),
                          "traffic": traffic,
                          "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes)" if traffic else None,
                          "kernel": (register_tile_kernel(launch) + (" (+ block_gram_kernel and tp_window_sums_kernel in front of it, every step)" if shared_blocks else ""))
-                                   if k <= 239 else "tiled pipeline (prior + prefix + gram + diag / TRSM / SYRK + solve)",
+                                   if k <= 239 else ("tiled pipeline (intraday block Grams + sums + prefix + gram + diag / TRSM / SYRK + solve)" if shared_hf else "tiled pipeline (prior + prefix + gram + diag / TRSM / SYRK + solve)"),
                          "kernel_ms": kernel_ms,
                          "step_ms": step_stats,
                          "alg_flops_per_window": alg_flops_per_window(k, n_r, m, conj),

@@ -171,6 +171,9 @@ int tp_batch_upload_wait(tp_batch_t b);                     /* host wait for the
 /* After an upload: the number of aligned row blocks of the daily panel whose Gram sums the windows of this batch share
  * (rolling windows in the contiguous layout); 0 when every window sums all its own rows. */
 int tp_batch_shared_gram_blocks(tp_batch_t b);
+/* After an upload, large-k path, conjugate: whole stride-long blocks of intraday rows per window whose Grams the windows
+ * of a sub-batch share (0: every intraday row of every window goes through the MFMAs). */
+int tp_batch_shared_intraday_blocks(tp_batch_t b);
 /* Page-locked host memory for panels and result arrays (hipHostMalloc): DMA at PCIe rate, asynchronous. */
 int tp_host_alloc(void** out, int64_t bytes);
 int tp_host_free(void* p);

@@ -40,6 +40,7 @@ EXPORTS = [
     "tp_device_info",
     "tp_log_returns", "tp_batch_create", "tp_batch_upload", "tp_batch_upload_async", "tp_batch_upload_wait",
     "tp_batch_shared_gram_blocks",
+    "tp_batch_shared_intraday_blocks",
     "tp_host_alloc", "tp_host_free", "tp_batch_set_rhs", "tp_batch_set_shift", "tp_batch_keep_rhs",
     "tp_batch_download_rhs", "tp_batch_run", "tp_batch_download", "tp_batch_download_S1", "tp_batch_download_matrix",
     "tp_batch_debug_stamps", "tp_batch_destroy", "tp_posterior_batch", "tp_synchronize", "tp_last_timing",
@@ -92,6 +93,7 @@ def _load():
     lib.tp_batch_upload_async.argtypes = [c_void_p, POINTER(tp_inputs_t)]
     lib.tp_batch_upload_wait.argtypes = [c_void_p]
     lib.tp_batch_shared_gram_blocks.argtypes = [c_void_p]
+    lib.tp_batch_shared_intraday_blocks.argtypes = [c_void_p]
     lib.tp_host_alloc.argtypes = [POINTER(c_void_p), c_int64]
     lib.tp_host_free.argtypes = [c_void_p]
     lib.tp_batch_keep_rhs.argtypes = [c_void_p, c_int]
@@ -472,6 +474,10 @@ class Batch:
     def shared_gram_blocks(self) -> int:
         """Aligned row blocks of the daily panel whose Gram sums this batch's windows share (0: none)."""
         return int(lib.tp_batch_shared_gram_blocks(self._b))
+
+    def shared_intraday_blocks(self) -> int:
+        """Large-k path, conjugate: whole intraday blocks (days) per window taken from shared block Grams (0: none)."""
+        return int(lib.tp_batch_shared_intraday_blocks(self._b))
 
     def keep_rhs(self, on=True):
         """Keep the right-hand side every window is solved for in later runs (`download_rhs` reads the last run's)."""

@@ -777,7 +777,7 @@ static int plan_shared_gram(tp_batch_t b, const tp_inputs_t* in) {
 }
 
 // Large-k path, conjugate: do the intraday windows qualify for shared sums (posterior_tiled_wave.h)?  Contiguous windows of
-// ONE length over ungathered columns, every start a fixed stride B after the previous one (rolling dates: one day of bars),
+// ONE length over ungathered columns, all starts a multiple of a stride B apart (rolling dates: one day of bars),
 // a contiguous daily layout without a risk-free adjustment (the kernel variant is built for that), and at least two whole
 // B-row blocks per window.  Blocks are aligned to the windows' ENDS: a window that starts behind a day's first bar
 // (its return is undefined, ref:311-312) ends on a day boundary.
@@ -790,10 +790,15 @@ static void plan_shared_hf(tp_batch_t b, const tp_inputs_t* in) {
     if ((p.flags & TP_FLAG_NO_SHARED_GRAM) || h->no_shared_gram) return;
     if (!in->hf_start || in->hf_row_idx || in->hf_count || in->col_idx || in->row_idx || in->rf_adj || !in->start) return;
     if (b->W < 4) return;
-    const long long B = in->hf_start[1] - in->hf_start[0];
+    // B: the largest stride all starts are multiples of (apart from a common offset) - the order of the windows in the
+    // batch does not matter, a reversed or shuffled batch takes the same decision and the same tables
+    long long B = 0;
+    for (int64_t w = 1; w < b->W; ++w) {
+        long long d = in->hf_start[w] - in->hf_start[0];
+        if (d < 0) d = -d;
+        while (d != 0) { const long long t = B % d; B = d; d = t; }       // B = gcd(B, d)
+    }
     if (B < 16 || B > 4096) return;
-    for (int64_t w = 1; w < b->W; ++w)
-        if (in->hf_start[w] - in->hf_start[w - 1] != B) return;
     const long long m = p.m;
     const long long ph = (in->hf_start[0] + m) % B;      // (start - ph > -B: the ceilings below stay exact)
     const long long f = in->hf_start[0];
@@ -937,6 +942,7 @@ int tp_host_free(void* p) {
 }
 
 int tp_batch_shared_gram_blocks(tp_batch_t b) { return b ? b->prefix_nblk : 0; }
+int tp_batch_shared_intraday_blocks(tp_batch_t b) { return (b && b->hf_B > 0) ? b->hf_L : 0; }
 
 int tp_batch_set_rhs(tp_batch_t b, const double* rhs) {
     if (!b) return TP_ERR_INVALID;
