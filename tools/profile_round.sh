@@ -17,6 +17,7 @@ python3 bench.py --strategy jeffreys --no-cpu-baseline --no-end-to-end > "$OUT/b
 python3 bench.py --config 1 --no-cpu-baseline --no-end-to-end > "$OUT/bench_c1.json" 2>> "$OUT/bench.err"
 python3 bench.py --config 3 --windows 4096 --steps 5 --warmup 1 --no-end-to-end > "$OUT/bench_c3.json" 2>> "$OUT/bench.err"
 python3 bench.py --config 5 --windows 384 --steps 3 --warmup 1 --no-end-to-end > "$OUT/bench_c5.json" 2>> "$OUT/bench.err"
+python3 bench.py --config 5 --windows 4096 --steps 2 --warmup 1 --no-end-to-end --no-cpu-baseline --no-general-layout > "$OUT/bench_c5_4096_windows.json" 2>> "$OUT/bench.err"
 echo "c3 / c5 done"
 # configs[2] at its stated 50,000 windows with the intraday panel NOT wrapped (15.6 GB), Jeffreys there for throughput
 # (singular at k=500 > N-2), and configs[3]'s per-GPU shard with the overlapped RCCL gather on a one-rank communicator
@@ -49,4 +50,4 @@ echo "pmc done"
 find "$OUT" -name "*_agent_info.csv" -delete
 find "$OUT" -name "*kernel_trace.csv" -delete
 python3 "$ROOT/tools/pmc_to_json.py" "$OUT" > "$OUT/pmc_traffic.json" 2> "$OUT/pmc_to_json.err" || echo "pmc_to_json failed"
-ls -R "$OUT" | head -80
+ls "$OUT"
