@@ -862,8 +862,8 @@ __global__ void __launch_bounds__(NTHREADS) tile64_syrk_trsm_kernel(const tp_kar
         }
     };
     double* buf0 = lds;
-    double* buf1 = lds + CH * LDX;
 #if TP_SYRK_DEPTH == 2
+    double* buf1 = lds + CH * LDX;
     double v2[8];
     if (nchunks > 0) { load(v, 0); store(buf0, v); }
     if (nchunks > 1) load(v, 1);

@@ -329,7 +329,7 @@ __device__ __forceinline__ void hfblock64_wave_body(const tp_kargs_t& A, const t
                                                     const long long tile, const int SI, const int SJ) {
     constexpr int NB = 4, NC = 8;
     const int lane = threadIdx.x;
-    const int fr = lane & 15, fq = lane >> 4;
+    const int fr = lane & 15;
     const int k = A.k;
     long long co[NC];
     double yb[NC], cs[NC];
