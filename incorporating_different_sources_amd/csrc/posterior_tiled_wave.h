@@ -38,7 +38,9 @@ __device__ __forceinline__ void tw_settle8(d4& c0, d4& c1, d4& c2, d4& c3, d4& c
 //  kernel: the A operands are loaded once for both)
 //  CS: also keep the column sums of the staged values (this lane's rows only) in cs[] - the Jeffreys rank-one term fused
 //  into the Gram kernel needs t = X'1 for the rows AND the columns of the super-tile (gram64_wave_body, RANK1)
-template <bool DIAG, bool EDGE, bool HF, int NB, bool CS = false>
+//  SUBR (!HF): subtract the reference row yb[] first (shared intraday sums: every row relative to ONE row of the panel, so
+//  that a common offset of the returns does not meet the rank-one centring term as a difference of large numbers)
+template <bool DIAG, bool EDGE, bool HF, int NB, bool CS = false, bool SUBR = false>
 __device__ __forceinline__ void tw_gram_pass(const TRows& src, const long long (&co)[4 + NB], const double (&yb)[4 + NB],
                                              const bool (&cval)[4 + NB], const bool (&cbord)[4 + NB], const double sqs, const int lane,
                                              d4 (&acc)[4 * NB], double (&cs)[4 + NB]) {
@@ -66,6 +68,10 @@ __device__ __forceinline__ void tw_gram_pass(const TRows& src, const long long (
                 if (EDGE) v[i] = cval[i] ? v[i] : (cbord[i] ? rc_ : 0.0);          // border: c sqrt(s) z_r
             }
         } else {
+            if constexpr (SUBR) {
+#pragma unroll
+                for (int i = 0; i < NO; ++i) v[i] -= yb[i];
+            }
             if (has_c) {
 #pragma unroll
                 for (int i = 0; i < NO; ++i) v[i] -= rc_;                          // x - rf (ref:57)
@@ -324,6 +330,14 @@ __global__ void __launch_bounds__(64, 2) tiled_gram_wave_kernel(const tp_kargs_t
 // and for I < J rows of J from the columns of I) to ws.part, and tiled_clear_kernel adds them up in a fixed order, forms
 // q0 = w0' S0 w0 and c (ref:415-418) and puts c S0 w0 into the border column.  No tiled_prior_kernel, no pass over the
 // intraday rows per window at all.
+// the reference row of the shared intraday sums: row 0 of the intraday panel (the same for every sub-batch and every batch
+// over this panel: results do not depend on how a run is cut); a non-finite entry counts as 0 (it must not poison windows
+// that do not contain it)
+__device__ __forceinline__ double tw_reference(const tp_kargs_t& A, const bool valid, const long long col) {
+    const double x = A.hf_panel[col];
+    return (valid && isfinite(x)) ? x : 0.0;
+}
+
 template <bool DIAG, bool EDGE>
 __device__ __forceinline__ void hfblock64_wave_body(const tp_kargs_t& A, const tp_tiled_ws_t& ws, double* out, const long long blk,
                                                     const long long tile, const int SI, const int SJ) {
@@ -341,7 +355,7 @@ __device__ __forceinline__ void hfblock64_wave_body(const tp_kargs_t& A, const t
         cval[i] = !EDGE || gc < k;
         cbord[i] = EDGE && gc == k;                                 // ones: the border column of a block Gram is its column sums
         co[i] = cval[i] ? gc : k - 1;
-        yb[i] = 0.0; cs[i] = 0.0;
+        yb[i] = tw_reference(A, cval[i], co[i]); cs[i] = 0.0;
     }
     d4 acc[4 * NB];
     static_for_t<0, 4 * NB>([&](auto tc) __attribute__((always_inline)) {
@@ -352,7 +366,7 @@ __device__ __forceinline__ void hfblock64_wave_body(const tp_kargs_t& A, const t
     hs.base = A.hf_panel; hs.ld = A.hf_ld; hs.ridx = nullptr; hs.rowc = nullptr;
     hs.first = A.hf_row0 + blk * A.hf_blk_rows;
     hs.count = A.hf_blk_rows; hs.count0 = 0x7fffffff; hs.jump = 0;
-    tw_gram_pass<DIAG, EDGE, false, NB>(hs, co, yb, cval, cbord, 0.0, lane, acc, cs);
+    tw_gram_pass<DIAG, EDGE, false, NB, false, true>(hs, co, yb, cval, cbord, 0.0, lane, acc, cs);
     typedef double d2 __attribute__((ext_vector_type(2)));
     const long long ntile = (long long)ws.NS * (ws.NS + 1) / 2;
     d2* p = (d2*)(out + (blk * ntile + tile) * (SB * SB)) + lane;
@@ -461,7 +475,7 @@ __device__ __forceinline__ void gram64_wave_hfs_body(const tp_kargs_t& A, const 
         cbord[i] = EDGE && gc == k;
         cnone[i] = false;
         co[i] = cval[i] ? gc : k - 1;
-        yb[i] = 0.0; cs[i] = 0.0;
+        yb[i] = tw_reference(A, cval[i], co[i]); cs[i] = 0.0;
     }
     pI[lane] = 0.0;
     pJ[lane] = 0.0;
@@ -481,7 +495,7 @@ __device__ __forceinline__ void gram64_wave_hfs_body(const tp_kargs_t& A, const 
         hs.count0 = (int)(A.hf_row0 + Bk * hb0 - hfirst);
         hs.jump = (int)(Bk * (hb1 - hb0));
         hs.count = hs.count0 + (int)(hfirst + mm - (A.hf_row0 + Bk * hb1));
-        tw_gram_pass<DIAG, EDGE, false, NB, true>(hs, co, yb, cval, cnone, 0.0, lane, acc, cs);
+        tw_gram_pass<DIAG, EDGE, false, NB, true, true>(hs, co, yb, cval, cnone, 0.0, lane, acc, cs);
     }
     const double* hq = A.hf_winsum + (hb0 * ntile) * (SB * SB);
     tw_build_t<DIAG>(cs, tv, true, hq + pair_index(SI, NS - 1, NS) * (SB * SB) + 2 * lane, hq + pair_index(SJ, NS - 1, NS) * (SB * SB) + 2 * lane,

@@ -378,3 +378,23 @@ def test_a_non_finite_intraday_row_poisons_only_the_windows_that_contain_it(nati
     assert (status[inside] != 0).all()
     assert (status[~inside] == 0).all()
     assert np.array_equal(got[~inside], clean[~inside])
+
+
+def test_shared_intraday_sums_with_a_large_common_offset(native):
+    """The shared sums are raw second moments made central by a rank-one term; every row is taken relative to ONE reference
+    row of the panel first, so an offset common to all returns (here 1.0 against a spread of 1e-3: a factor 1e6 between the
+    raw and the central moments) costs no digits.  Flat 1e-10 against the oracle's two-pass form."""
+    k, N, hf_days, W = 260, 300, 8, 24
+    inp = synthetic.make_kernel_inputs(k, N, W, seed=6300, hf_days=hf_days)
+    hf = inp["hf_panel"] + 1.0
+    kw = dict(panel=inp["panel"], start=inp["start"], n_r=inp["n_r"], hf_panel=hf, hf_start=inp["hf_start"],
+              m=inp["m"], w0=inp["w0"], n0=inp["n0"])
+    wts, status, aux = native.posterior_batch("conjugate", k, N, 5.0, **kw)
+    plain, pstat, paux = native.posterior_batch("conjugate", k, N, 5.0, flags=native.FLAG_NO_SHARED_GRAM, **kw)
+    assert (status == 0).all() and (pstat == 0).all() and not np.array_equal(wts, plain)
+    sel = np.array([0, 5, W - 1])
+    sub = {key: (val[sel] if key in ("start", "hf_start", "w0", "n0") else val) for key, val in kw.items()}
+    ref, rstat, raux = oracle.posterior_batch_c("conjugate", k, N, 5.0, **sub)
+    np.testing.assert_allclose(plain[sel], ref, **WTOL)
+    np.testing.assert_allclose(wts[sel], ref, **WTOL)
+    np.testing.assert_allclose(aux[sel, :6], raux[:, :6], rtol=1e-10, atol=1e-14)
