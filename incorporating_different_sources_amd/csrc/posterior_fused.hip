@@ -45,8 +45,12 @@ hipError_t tp_fused_launch(const tp_kargs_t& a, int grid, hipStream_t stream, tp
 // for L <= 16) and Q_L[b0] = (S[i] + M) + P[i] contains the blocks of ITS window and nothing else; its rounding depends on
 // the panel, b0 and L alone.
 typedef double tp_d2 __attribute__((ext_vector_type(2)));
+// abs0: the ABSOLUTE block index of table position 0 (the large-k path builds tables for the blocks of the sub-batch in flight
+// only).  Groups are cut in absolute positions - multiples of the group length - so Q_L of a block position is the same
+// sequence of additions whichever range a table covers; the first group of a table may start below position 0 (its
+// positions and blocks there are skipped: a position p >= 0 only needs blocks >= p).
 __global__ void __launch_bounds__(256) tp_window_sums_kernel(const tp_d2* __restrict__ G, tp_d2* __restrict__ Q, int nblk,
-                                                             long long slot_pairs, int4 Ls, int n_L) {
+                                                             long long slot_pairs, int4 Ls, int n_L, long long abs0) {
     constexpr int R = TP_WINSUM_RUN;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= slot_pairs) return;
@@ -55,7 +59,7 @@ __global__ void __launch_bounds__(256) tp_window_sums_kernel(const tp_d2* __rest
     if (li >= n_L || L < 1) return;
     const int npos = nblk - L + 1;                          // positions b0 with b0 + L <= nblk
     const int Rr = L < R ? L : R;                           // group length
-    const int g = blockIdx.y * Rr;
+    const int g = (int)(((long long)blockIdx.y) * Rr - abs0 % Rr);          // table position of the group's first block (>= -Rr + 1)
     if (g >= npos) return;
     const tp_d2* Ge = G + e;
     tp_d2* out = Q + (long long)li * nblk * slot_pairs + e;
@@ -63,34 +67,37 @@ __global__ void __launch_bounds__(256) tp_window_sums_kernel(const tp_d2* __rest
     tp_d2 run = tp_d2{0.0, 0.0};
 #pragma unroll
     for (int i = R - 1; i >= 0; --i) {                      // suffix sums of the group's own blocks (g + i <= nblk - 1)
-        if (i < Rr) run += Ge[(long long)(g + i) * slot_pairs];
+        if (i < Rr && g + i >= 0) run += Ge[(long long)(g + i) * slot_pairs];
         S[i] = run;
     }
     tp_d2 M = tp_d2{0.0, 0.0};
     for (int b = g + Rr; b < g + L; ++b) M += Ge[(long long)b * slot_pairs];      // empty for L <= 16
-    out[(long long)g * slot_pairs] = S[0] + M;
+    if (g >= 0) out[(long long)g * slot_pairs] = S[0] + M;
     tp_d2 P = tp_d2{0.0, 0.0};
 #pragma unroll
     for (int i = 1; i < R; ++i) {
         if (i < Rr && g + i < npos) {
             P += Ge[(long long)(g + L + i - 1) * slot_pairs];
-            out[(long long)(g + i) * slot_pairs] = (S[i] + M) + P;
+            if (g + i >= 0) out[(long long)(g + i) * slot_pairs] = (S[i] + M) + P;
         }
     }
 }
 
 hipError_t tp_window_sums_launch(const double* G, double* Q, int nblk, size_t slot_doubles, const int* L, int n_L,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, long long abs0) {
     if (n_L < 1 || nblk < 1) return hipSuccess;
     const long long slot_pairs = (long long)(slot_doubles / 2);
     int groups = 1;                                         // the largest group count among the tables
     for (int i = 0; i < n_L; ++i) {
         const int Rr = L[i] < TP_WINSUM_RUN ? L[i] : TP_WINSUM_RUN;
         const int npos = nblk - L[i] + 1;
-        if (Rr >= 1 && npos >= 1 && (npos + Rr - 1) / Rr > groups) groups = (npos + Rr - 1) / Rr;
+        if (Rr >= 1 && npos >= 1) {
+            const long long gcount = (abs0 % Rr + npos + Rr - 1) / Rr;
+            if (gcount > groups) groups = (int)gcount;
+        }
     }
     const int4 Ls = make_int4(L[0], n_L > 1 ? L[1] : 0, n_L > 2 ? L[2] : 0, n_L > 3 ? L[3] : 0);
     hipLaunchKernelGGL(tp_window_sums_kernel, dim3((unsigned)((slot_pairs + 255) / 256), (unsigned)groups, (unsigned)n_L), dim3(256), 0,
-                       stream, (const tp_d2*)G, (tp_d2*)Q, nblk, slot_pairs, Ls, n_L);
+                       stream, (const tp_d2*)G, (tp_d2*)Q, nblk, slot_pairs, Ls, n_L, abs0);
     return hipGetLastError();
 }

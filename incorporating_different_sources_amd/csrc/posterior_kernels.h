@@ -51,6 +51,8 @@ struct tp_kargs_t {
     const double* prefix; // optional (contiguous layout, no rf_adj): workspace of the shared Gram sums of the daily panel:
                           // the per-block Grams G[prefix_nblk][slot], filled by every launch before the window kernel
     int prefix_nblk;      // whole TP_PREFIX_BLOCK_ROWS-row blocks of the panel
+    int prefix_blk0;      // large-k path: the tables cover blocks prefix_blk0 .. prefix_blk0 + prefix_nblk - 1 (those of the
+                          // sub-batch in flight; a whole-panel table at k = 1000 and 125,000 windows would be 102 GB); else 0
     // behind the block Grams: one table of block-window sums Q_L[b0] = G[b0] + .. + G[b0 + L - 1] per whole-block count
     // L that occurs among the batch's windows (at most TP_WINSUM_MAX_L)
     const double* winsum; // Q tables: [n_L][prefix_nblk][slot]
@@ -98,8 +100,9 @@ inline size_t tp_fused_prefix_bytes(int k, long long panel_rows, int n_L, int* n
     return sizeof(double) * (size_t)nblk * (size_t)(1 + n_L) * tp_fused_slot_doubles(k);
 }
 // Q_L tables from the block Grams (posterior_fused.hip): elementwise, additions only, groups of TP_WINSUM_RUN positions
+// abs0: absolute block index of table position 0 (groups are cut in absolute positions: posterior_fused.hip)
 hipError_t tp_window_sums_launch(const double* G, double* Q, int nblk, size_t slot_doubles, const int* L, int n_L,
-                                 hipStream_t stream);
+                                 hipStream_t stream, long long abs0 = 0);
 
 // which register-tile kernel runs a tile count: 0 = the multi-wave kernel (posterior_fused_impl.h), 1 = one wave per
 // window (posterior_wave_impl.h), 2 = two / four waves per window (posterior_wave2_impl.h); `choice` =

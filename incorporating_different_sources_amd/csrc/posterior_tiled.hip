@@ -410,7 +410,8 @@ __device__ __forceinline__ void gram64_lean_body(const tp_kargs_t& A, const tp_t
     const long long pb0 = (dfirst + CH - 1) / CH, pb1 = (dfirst + nr) / CH;
     const int Lw = (int)(pb1 - pb0);         // whole blocks of this window; the host planned a table for its count
     const int li = Lw == A.winsum_L[0] ? 0 : Lw == A.winsum_L[1] ? 1 : Lw == A.winsum_L[2] ? 2 : Lw == A.winsum_L[3] ? 3 : -1;
-    const bool shared = A.winsum != nullptr && !dridx && Lw > 0 && li >= 0;
+    const long long tb0 = pb0 - A.prefix_blk0;                    // position in the tables of the sub-batch in flight
+    const bool shared = A.winsum != nullptr && !dridx && Lw > 0 && li >= 0 && tb0 >= 0 && tb0 + Lw <= A.prefix_nblk;
     const int lo = shared ? (int)(CH * pb0 - dfirst) : nr;            // staged daily rows r < lo: window rows r
     const int djump = shared ? (int)(CH * pb1 - dfirst) - lo : 0;     //                  r >= lo: window rows r + djump
     const int nrs = shared ? lo + (int)(dfirst + nr - CH * pb1) : nr; // staged daily rows
@@ -491,7 +492,7 @@ __device__ __forceinline__ void gram64_lean_body(const tp_kargs_t& A, const tp_t
         const long long tile = pair_index(SI, SJ, ws.NS);
         // [..][wave][16-column group b][2][64 lanes][2]: registers (0,1) and (2,3) of a lane are 16 contiguous bytes
         typedef double d2 __attribute__((ext_vector_type(2)));
-        const d2* q = (const d2*)(A.winsum + (((long long)li * A.prefix_nblk + pb0) * ntile + tile) * (SB * SB) + wv * 1024) + lane;
+        const d2* q = (const d2*)(A.winsum + (((long long)li * A.prefix_nblk + tb0) * ntile + tile) * (SB * SB) + wv * 1024) + lane;
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -519,7 +520,7 @@ __device__ __forceinline__ void blockgram64_body(const tp_kargs_t& A, const tp_t
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int k = A.k;
-    const double* row = A.panel + (blk * CH + (tid >> 4)) * (long long)A.panel_ld;
+    const double* row = A.panel + ((blk + A.prefix_blk0) * CH + (tid >> 4)) * (long long)A.panel_ld;
     const int cb = tid & 15;
     double v[8];
 #pragma unroll
@@ -966,7 +967,7 @@ hipError_t tp_tiled_prefix_launch(const tp_kargs_t& a, const tp_tiled_ws_t& ws, 
     int n_L = 0;
     while (n_L < TP_WINSUM_MAX_L && a.winsum_L[n_L] > 0) ++n_L;
     return tp_window_sums_launch(a.prefix, (double*)a.winsum, a.prefix_nblk, (size_t)(NS * (NS + 1) / 2) * SB * SB, a.winsum_L, n_L,
-                                 stream);
+                                 stream, a.prefix_blk0);
 }
 
 hipError_t tp_tiled_launch(const tp_kargs_t& a_in, const tp_tiled_ws_t& ws, hipStream_t stream, bool build_prefix) {

@@ -199,7 +199,8 @@ __device__ __forceinline__ void gram64_wave_body(const tp_kargs_t& A, const tp_t
     const long long pb0 = (ds.first + CH - 1) / CH, pb1 = (ds.first + nr) / CH;
     const int Lw = (int)(pb1 - pb0);
     const int li = Lw == A.winsum_L[0] ? 0 : Lw == A.winsum_L[1] ? 1 : Lw == A.winsum_L[2] ? 2 : Lw == A.winsum_L[3] ? 3 : -1;
-    const bool shared = A.winsum != nullptr && !ds.ridx && Lw > 0 && li >= 0;
+    const long long tb0 = pb0 - A.prefix_blk0;                    // position in the tables of the sub-batch in flight
+    const bool shared = A.winsum != nullptr && !ds.ridx && Lw > 0 && li >= 0 && tb0 >= 0 && tb0 + Lw <= A.prefix_nblk;
     if (shared) {
         ds.count0 = (int)(CH * pb0 - ds.first);
         ds.jump = (int)(CH * pb1 - ds.first) - ds.count0;
@@ -241,7 +242,7 @@ __device__ __forceinline__ void gram64_wave_body(const tp_kargs_t& A, const tp_t
 #pragma unroll
                 for (int side = 0; side < (DIAG ? 1 : 2); ++side) {
                     const int S = side == 0 ? SI : SJ;
-                    const d2* qb = (const d2*)(A.winsum + (((long long)li * A.prefix_nblk + pb0) * ntile + pair_index(S, ws.NS - 1, ws.NS)) * (SB * SB)) + lane;
+                    const d2* qb = (const d2*)(A.winsum + (((long long)li * A.prefix_nblk + tb0) * ntile + pair_index(S, ws.NS - 1, ws.NS)) * (SB * SB)) + lane;
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         const d2 lo = qb[a * 512 + (bk * 2 + 0) * 64], hi = qb[a * 512 + (bk * 2 + 1) * 64];
@@ -266,7 +267,7 @@ __device__ __forceinline__ void gram64_wave_body(const tp_kargs_t& A, const tp_t
         for (int b = 0; b < NB; ++b) tj[b] = tv_lds[64 + 16 * b + fr];
     }
     // (the super-tiles of a pair are neighbours in the row-major numbering of the triangle: slot of (SI, SJ + 1) = slot + 1)
-    const d2* q = shared ? (const d2*)(A.winsum + (((long long)li * A.prefix_nblk + pb0) * ntile + pair_index(SI, SJ, ws.NS)) * (SB * SB)) + lane
+    const d2* q = shared ? (const d2*)(A.winsum + (((long long)li * A.prefix_nblk + tb0) * ntile + pair_index(SI, SJ, ws.NS)) * (SB * SB)) + lane
                          : nullptr;
     static_for_t<0, 4>([&](auto ac) __attribute__((always_inline)) {
         constexpr int a = decltype(ac)::value;
@@ -584,14 +585,15 @@ __device__ __forceinline__ void gram64_wave_hfs_body(const tp_kargs_t& A, const 
     const long long pb0 = (ds.first + CH - 1) / CH, pb1 = (ds.first + nr) / CH;
     const int Lw = (int)(pb1 - pb0);
     const int li = Lw == A.winsum_L[0] ? 0 : Lw == A.winsum_L[1] ? 1 : Lw == A.winsum_L[2] ? 2 : Lw == A.winsum_L[3] ? 3 : -1;
-    const bool shared = A.winsum != nullptr && Lw > 0 && li >= 0;
+    const long long tb0 = pb0 - A.prefix_blk0;
+    const bool shared = A.winsum != nullptr && Lw > 0 && li >= 0 && tb0 >= 0 && tb0 + Lw <= A.prefix_nblk;
     if (shared) {
         ds.count0 = (int)(CH * pb0 - ds.first);
         ds.jump = (int)(CH * pb1 - ds.first) - ds.count0;
         ds.count = ds.count0 + (int)(ds.first + nr - CH * pb1);
     }
     tw_gram_pass<DIAG, EDGE, false, NB>(ds, co, yb, cval, cbord, 0.0, lane, acc, cs);
-    const d2* q = shared ? (const d2*)(A.winsum + (((long long)li * A.prefix_nblk + pb0) * ntile + pair_index(SI, SJ, NS)) * (SB * SB)) + lane
+    const d2* q = shared ? (const d2*)(A.winsum + (((long long)li * A.prefix_nblk + tb0) * ntile + pair_index(SI, SJ, NS)) * (SB * SB)) + lane
                          : nullptr;
     static_for_t<0, 4>([&](auto ac) __attribute__((always_inline)) {
         constexpr int a = decltype(ac)::value;

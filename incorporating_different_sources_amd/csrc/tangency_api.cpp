@@ -92,6 +92,11 @@ struct tp_batch_s {
         t_flags[TP_MAX_LANES];                                // large-k path workspace, one per lane
     // large-k path, conjugate: shared intraday sums (posterior_tiled_wave.h).  Decided at upload (plan_shared_hf): the
     // windows' intraday rows are contiguous, of one length, and advance by hf_B rows; the tables are per sub-batch
+    // large-k path: the daily tables cover the blocks of the sub-batch in flight (plan_daily_tables); host copies of
+    // what the block ranges are computed from
+    bool prefix_per_sub = false;
+    std::vector<int64_t> h_start;
+    std::vector<int32_t> h_n_rows;
     std::vector<int64_t> h_hf_start;                          // host copy of hf_start (the sub-batches' block ranges)
     int hf_B = 0, hf_L = 0;                                   // rows per block (0 = not shared), whole blocks per window
     long long hf_phase = 0;                                   // blocks start at rows = hf_phase (mod hf_B)
@@ -233,11 +238,12 @@ tp_kargs_t make_kargs(tp_batch_t b) {
     a.hf_count = (const int*)b->hf_count.p;
     a.w0 = (const double*)b->w0.p;
     a.n0 = (const double*)b->n0.p;
-    a.prefix = b->prefix_nblk > 0 ? (const double*)b->prefix.p : nullptr;
-    a.prefix_nblk = b->prefix_nblk;
+    a.prefix = (b->prefix_nblk > 0 && !b->prefix_per_sub) ? (const double*)b->prefix.p : nullptr;
+    a.prefix_nblk = b->prefix_per_sub ? 0 : b->prefix_nblk;
+    a.prefix_blk0 = 0;
     a.winsum = nullptr;
     for (int i = 0; i < 4; ++i) a.winsum_L[i] = 0;
-    if (b->prefix_nblk > 0) {      // block Grams first, the block-window tables behind them
+    if (b->prefix_nblk > 0 && !b->prefix_per_sub) {      // block Grams first, the block-window tables behind them
         const size_t slot = b->p.k <= tp_fused_max_assets() ? tp_fused_slot_doubles(b->p.k) : tp_tiled_slot_doubles(b->p.k);
         a.winsum = (const double*)b->prefix.p + (size_t)b->prefix_nblk * slot;
         for (int i = 0; i < 4; ++i) a.winsum_L[i] = b->winsum_L[i];
@@ -406,6 +412,47 @@ int ensure_tiled_ws(tp_batch_t b, tp_tiled_ws_t* ws, int* lanes_out) {
     return TP_OK;
 }
 
+// Shared daily sums of the large-k path for ONE sub-batch (or, `whole`, for the whole panel: several lanes in flight): the
+// 16-row blocks its windows cover, block Grams first, one table of block-window sums per whole-block count behind them.
+int plan_daily_tables(tp_batch_t b, tp_kargs_t& sub, bool whole) {
+    tp_handle_t h = b->h;
+    sub.prefix = nullptr; sub.winsum = nullptr; sub.prefix_nblk = 0; sub.prefix_blk0 = 0;
+    for (int i = 0; i < 4; ++i) sub.winsum_L[i] = 0;
+    long long lo = 0, hi = b->prefix_nblk;
+    if (!whole) {
+        lo = 0x7fffffffffffffffLL; hi = -1;
+        for (int64_t w = sub.w_first; w < sub.w_first + sub.w_count; ++w) {
+            const long long f = b->h_start[(size_t)w], cnt = b->h_n_rows.empty() ? b->p.n_r : b->h_n_rows[(size_t)w];
+            const long long b0 = (f + 15) / 16, b1 = (f + cnt) / 16;
+            if (b1 <= b0) continue;
+            if (b0 < lo) lo = b0;
+            if (b1 > hi) hi = b1;
+        }
+        if (hi <= lo) return TP_OK;
+        if (hi > b->prefix_nblk) hi = b->prefix_nblk;
+        // sharing pays while the windows' rows outnumber the rows of the blocks a few times over
+        if ((double)sub.w_count * b->p.n_r < 3.0 * 16.0 * (double)(hi - lo)) return TP_OK;
+    }
+    const long long nblk = hi - lo;
+    int n_L = 0;
+    while (n_L < TP_WINSUM_MAX_L && b->winsum_L[n_L] > 0) ++n_L;
+    if (nblk < 1 || nblk > 0x3fffffff || n_L == 0) return TP_OK;
+    const size_t slot = tp_tiled_slot_doubles(b->p.k);
+    const size_t bytes = sizeof(double) * (size_t)nblk * (size_t)(1 + n_L) * slot;
+    if (bytes > b->prefix.bytes) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > (free_b + b->prefix.bytes) / 3) return TP_OK;
+        int rc = ensure(h, b->prefix, bytes);
+        if (rc != TP_OK) return rc;
+    }
+    sub.prefix = (const double*)b->prefix.p;
+    sub.winsum = (const double*)b->prefix.p + (size_t)nblk * slot;
+    sub.prefix_nblk = (int)nblk;
+    sub.prefix_blk0 = (int)lo;
+    for (int i = 0; i < 4; ++i) sub.winsum_L[i] = b->winsum_L[i];
+    return TP_OK;
+}
+
 // Shared intraday sums of ONE sub-batch (windows sub.w_first .. + sub.w_count): the block range its windows cover, the
 // tables sized for it (block Grams, then the block-window sums).  A sub-batch whose windows do not all have hf_L whole blocks
 // inside one affordable range keeps the two-pass form (sub.hf_winsum stays null).
@@ -479,24 +526,32 @@ int launch(tp_batch_t b, const tp_kargs_t& a, int64_t count, bool timed) {
     if (rc != TP_OK) return rc;
     if (lanes > 1) { rc = ensure_lane_streams(h, lanes); if (rc != TP_OK) return rc; }
     if (timed) HIP_TRY(h, hipEventRecord(t0, h->stream));
+    tp_kargs_t whole = a;
+    if (lanes > 1 && b->prefix_per_sub) { rc = plan_daily_tables(b, whole, true); if (rc != TP_OK) return rc; }
     if (lanes > 1) {
         // the shared sums once, on the kernel stream; then every lane's stream starts behind them
-        hipError_t e = tp_tiled_prefix_launch(a, ws[0], h->stream);
+        hipError_t e = tp_tiled_prefix_launch(whole, ws[0], h->stream);
         if (e != hipSuccess) return fail(h, TP_ERR_HIP, "tiled pipeline launch failed: %s", hipGetErrorString(e));
         HIP_TRY(h, hipEventRecord(h->lane_start, h->stream));
         for (int l = 0; l < lanes; ++l) HIP_TRY(h, hipStreamWaitEvent(h->lane_stream[l], h->lane_start, 0));
     }
     int64_t sb = 0;
     for (int64_t w0 = 0; w0 < count; w0 += b->tiled_capacity, ++sb) {
-        tp_kargs_t sub = a;
+        tp_kargs_t sub = lanes > 1 ? whole : a;
         sub.w_first = a.w_first + w0;
         sub.w_count = (count - w0 < b->tiled_capacity) ? (count - w0) : b->tiled_capacity;
         const int l = (int)(sb % lanes);
+        if (b->prefix_per_sub && lanes == 1) {
+            rc = plan_daily_tables(b, sub, false);
+            if (rc != TP_OK) return rc;
+        }
         if (b->hf_B > 0 && lanes == 1 && a.strategy == TP_STRATEGY_CONJUGATE) {
             rc = plan_hf_tables(b, sub);
             if (rc != TP_OK) return rc;
         }
-        hipError_t e = tp_tiled_launch(sub, ws[l], lanes > 1 ? h->lane_stream[l] : h->stream, lanes == 1 && w0 == 0);
+        // (per-sub-batch tables: every sub-batch builds its own; a whole-panel table: the first one builds it)
+        hipError_t e = tp_tiled_launch(sub, ws[l], lanes > 1 ? h->lane_stream[l] : h->stream,
+                                       lanes == 1 && (b->prefix_per_sub || w0 == 0));
         if (e != hipSuccess) return fail(h, TP_ERR_HIP, "tiled pipeline launch failed: %s", hipGetErrorString(e));
     }
     if (lanes > 1) {
@@ -739,6 +794,8 @@ int tp_batch_destroy(tp_batch_t b) {
 static int plan_shared_gram(tp_batch_t b, const tp_inputs_t* in) {
     tp_handle_t h = b->h;
     b->prefix_nblk = 0;
+    b->prefix_per_sub = false;
+    b->h_start.clear(); b->h_n_rows.clear();
     const tp_params_t& p = b->p;
     if ((p.flags & TP_FLAG_NO_SHARED_GRAM) || h->no_shared_gram) return TP_OK;
     if (in->row_idx || in->col_idx || in->rf_adj || !in->start) return TP_OK;
@@ -767,6 +824,16 @@ static int plan_shared_gram(tp_batch_t b, const tp_inputs_t* in) {
         bytes = fused ? tp_fused_prefix_bytes(p.k, rows, n_L, &nblk) : tp_tiled_prefix_bytes(p.k, rows, n_L, &nblk);
     }
     if (nblk < 2 || (double)b->W * p.n_r < 3.0 * (double)rows) return TP_OK;
+    if (p.k > tp_fused_max_assets()) {
+        // large-k path: a slot is megabytes (4.35 MB at k = 1000), a table over the whole panel of a long run does not fit
+        // (102 GB at 125,000 windows) - the tables are built per sub-batch, for the blocks its windows cover
+        if ((size_t)in->panel_ld * 8 * 4096 >= (1ull << 32)) return TP_OK;
+        b->prefix_per_sub = true;
+        b->prefix_nblk = nblk;
+        b->h_start.assign(in->start, in->start + b->W);
+        if (in->n_rows) b->h_n_rows.assign(in->n_rows, in->n_rows + b->W);
+        return TP_OK;
+    }
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 3) return TP_OK;   // never crowd out the batch itself
     if ((size_t)in->panel_ld * 8 * 4096 >= (1ull << 32)) return TP_OK;      // 32-bit offsets inside a segment

@@ -398,3 +398,34 @@ def test_shared_intraday_sums_with_a_large_common_offset(native):
     np.testing.assert_allclose(plain[sel], ref, **WTOL)
     np.testing.assert_allclose(wts[sel], ref, **WTOL)
     np.testing.assert_allclose(aux[sel, :6], raux[:, :6], rtol=1e-10, atol=1e-14)
+
+
+@pytest.mark.parametrize("strat,hf_days", [("conjugate", 8), ("conjugate", 2), ("jeffreys", 1)])
+def test_large_k_tables_per_sub_batch_do_not_depend_on_the_cut(native, strat, hf_days):
+    """The large-k path builds its shared tables (daily block-window sums, intraday block Grams) for the blocks of the
+    sub-batch in flight.  A run cut into many small sub-batches (a 48 MiB arena: ~50 windows each) must give bit for bit what
+    one sub-batch gives: block Grams depend on the panel only and the sums' groups are cut in absolute block positions."""
+    k, N, W = 300, 700 if strat == "jeffreys" else 320, 230
+    inp = synthetic.make_kernel_inputs(k, N, W, seed=6400 + hf_days, hf_days=hf_days)
+    kw = dict(panel=inp["panel"], start=inp["start"], n_r=inp["n_r"])
+    if strat == "conjugate":
+        kw.update(hf_panel=inp["hf_panel"], hf_start=inp["hf_start"], m=inp["m"], w0=inp["w0"], n0=inp["n0"])
+    dev = native.default_device()
+    one, s1, a1 = native.posterior_batch(strat, k, N, 5.0, **kw)
+    dev.set_option("tiled_arena_mib", 48)
+    try:
+        b = dev.batch(strat, k, N, inp["n_r"], 5.0, W, inp["m"] if strat == "conjugate" else 0)
+        try:
+            b.upload(**{key: val for key, val in kw.items() if key not in ("n_r", "m")})
+            b.run()
+            cut, s2, a2 = b.download()
+            assert dev.last_launch()["grid"] < W // 3           # several sub-batches
+        finally:
+            b.close()
+    finally:
+        dev.set_option("tiled_arena_mib", 0)
+    assert (s1 == 0).all() and (s2 == 0).all()
+    assert np.array_equal(one, cut) and np.array_equal(a1, a2)
+    plain, _, _ = native.posterior_batch(strat, k, N, 5.0, flags=native.FLAG_NO_SHARED_GRAM, **kw)
+    assert not np.array_equal(one, plain)                       # the shared tables were in use
+    np.testing.assert_allclose(one, plain, rtol=0, atol=1e-12 * max(1.0, np.abs(plain).max()))
