@@ -4,4 +4,4 @@ Host modules keep the reference's call surface (`portfolio_specs`, `portfolio_ca
 arithmetic of the hot path runs in hand-written HIP kernels behind a C-ABI (`libtangency.so`,
 `include/tangency_posterior.h`).  There is no CPU fallback.
 """
-__version__ = "0.5.0"   # = the number in tp_version() (tests/test_cabi_symbols.py checks)
+__version__ = "0.6.0"   # = the number in tp_version() (tests/test_cabi_symbols.py checks)

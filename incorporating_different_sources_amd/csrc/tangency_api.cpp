@@ -635,7 +635,7 @@ int destroy_handle(tp_handle_t h, bool device_calls) {
 
 extern "C" {
 
-const char* tp_version(void) { return "tangency-posterior 0.5.0 (gfx950, fp64 MFMA: one wavefront per window k<=143, two or four per window k<=239, tiled pipeline k<=2047)"; }
+const char* tp_version(void) { return "tangency-posterior 0.6.0 (gfx950, fp64 MFMA: one wavefront per window k<=143, two or four per window k<=239, tiled pipeline k<=2047 with shared daily and intraday block Grams)"; }
 
 int tp_max_assets(void) { return tp_tiled_max_assets(); }
 
