@@ -824,6 +824,9 @@ static int plan_shared_gram(tp_batch_t b, const tp_inputs_t* in) {
         bytes = fused ? tp_fused_prefix_bytes(p.k, rows, n_L, &nblk) : tp_tiled_prefix_bytes(p.k, rows, n_L, &nblk);
     }
     if (nblk < 2 || (double)b->W * p.n_r < 3.0 * (double)rows) return TP_OK;
+    // a handful of tiny windows: the two extra launches cost more than the rows they save (configs[0], k = 10, 100 windows:
+    // 28.6 us with the shared sums, 21.5 us without)
+    if (p.k <= 31 && b->W < 256) return TP_OK;
     if (p.k > tp_fused_max_assets()) {
         // large-k path: a slot is megabytes (4.35 MB at k = 1000), a table over the whole panel of a long run does not fit
         // (102 GB at 125,000 windows) - the tables are built per sub-batch, for the blocks its windows cover

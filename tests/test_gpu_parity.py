@@ -394,7 +394,7 @@ def test_layouts_are_bitwise_equivalent(native, k, N, hf_days):
         np.testing.assert_allclose(j3, j1, rtol=0, atol=1e-11 * max(1.0, np.abs(j1).max()))
 
 
-@pytest.mark.parametrize("k,N,hf_days,strat,W", [(7, 600, 1, "conjugate", 40), (100, 250, 1, "conjugate", 300),
+@pytest.mark.parametrize("k,N,hf_days,strat,W", [(7, 600, 1, "conjugate", 450), (100, 250, 1, "conjugate", 300),
                                                  (130, 700, 2, "jeffreys", 50), (200, 1200, 3, "conjugate", 20),
                                                  (240, 300, 2, "conjugate", 40), (300, 700, 1, "jeffreys", 30),
                                                  (500, 250, 5, "conjugate", 48), (1000, 500, 22, "conjugate", 20),
