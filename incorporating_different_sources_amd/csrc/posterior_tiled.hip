@@ -989,7 +989,7 @@ hipError_t tp_tiled_launch(const tp_kargs_t& a_in, const tp_tiled_ws_t& ws, hipS
     if (!hfs) a.hf_winsum = nullptr;
     if (hfs) {
         const long long ntile = (long long)NS * (NS + 1) / 2;
-        hipLaunchKernelGGL(tiled_hf_block_gram_kernel, dim3((unsigned)(a.hf_nblk * ntile)), dim3(64), 0, stream, a, ws, (double*)a.hf_prefix);
+        hipLaunchKernelGGL(tiled_hf_block_gram_kernel, xcd_grid((int)ntile, a.hf_nblk), dim3(64), 0, stream, a, ws, (double*)a.hf_prefix);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         e = tp_window_sums_launch(a.hf_prefix, (double*)a.hf_winsum, a.hf_nblk, tp_tiled_slot_doubles(a.k), &a.hf_L, 1, stream);

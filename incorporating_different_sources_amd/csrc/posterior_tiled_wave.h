@@ -41,7 +41,7 @@ __device__ __forceinline__ void tw_settle8(d4& c0, d4& c1, d4& c2, d4& c3, d4& c
 //  SUBR (!HF): subtract the reference row yb[] first (shared intraday sums: every row relative to ONE row of the panel, so
 //  that a common offset of the returns does not meet the rank-one centring term as a difference of large numbers)
 template <bool DIAG, bool EDGE, bool HF, int NB, bool CS = false, bool SUBR = false>
-__device__ __forceinline__ void tw_gram_pass(const TRows& src, const long long (&co)[4 + NB], const double (&yb)[4 + NB],
+__device__ __forceinline__ void tw_gram_pass(const TRows& src, const int (&co)[4 + NB], const double (&yb)[4 + NB],
                                              const bool (&cval)[4 + NB], const bool (&cbord)[4 + NB], const double sqs, const int lane,
                                              d4 (&acc)[4 * NB], double (&cs)[4 + NB]) {
     constexpr int NO = DIAG ? NB : 4 + NB;      // operand registers per k-step (a diagonal super-tile: its B groups are the A groups)
@@ -153,7 +153,7 @@ __device__ __forceinline__ void gram64_wave_body(const tp_kargs_t& A, const tp_t
     const double sqs = conj ? ws.scal[wl * 8 + 1] : 0.0;
     const double* ybar = ws.ybar + wl * KP;
 
-    long long co[NC];
+    int co[NC];
     double yb[NC];
     bool cval[NC], cbord[NC];
 #pragma unroll
@@ -165,7 +165,7 @@ __device__ __forceinline__ void gram64_wave_body(const tp_kargs_t& A, const tp_t
         cval[i] = !EDGE || gc < k;
         cbord[i] = EDGE && gc == k;
         const int gcl = cval[i] ? gc : k - 1;                      // padding columns re-read column k-1 (masked)
-        co[i] = cols ? (long long)cols[gcl] : (long long)gcl;
+        co[i] = cols ? cols[gcl] : gcl;
         yb[i] = (conj && cval[i]) ? ybar[gcl] : 0.0;
     }
     d4 acc[4 * NB];
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(64, 2) tiled_gram_wave_kernel(const tp_kargs_t
 // the reference row of the shared intraday sums: row 0 of the intraday panel (the same for every sub-batch and every batch
 // over this panel: results do not depend on how a run is cut); a non-finite entry counts as 0 (it must not poison windows
 // that do not contain it)
-__device__ __forceinline__ double tw_reference(const tp_kargs_t& A, const bool valid, const long long col) {
+__device__ __forceinline__ double tw_reference(const tp_kargs_t& A, const bool valid, const int col) {
     const double x = A.hf_panel[col];
     return (valid && isfinite(x)) ? x : 0.0;
 }
@@ -346,7 +346,7 @@ __device__ __forceinline__ void hfblock64_wave_body(const tp_kargs_t& A, const t
     const int lane = threadIdx.x;
     const int fr = lane & 15;
     const int k = A.k;
-    long long co[NC];
+    int co[NC];
     double yb[NC], cs[NC];
     bool cval[NC], cbord[NC];
 #pragma unroll
@@ -383,10 +383,12 @@ __device__ __forceinline__ void hfblock64_wave_body(const tp_kargs_t& A, const t
 }
 
 __global__ void __launch_bounds__(64, 2) tiled_hf_block_gram_kernel(const tp_kargs_t A, const tp_tiled_ws_t ws, double* out) {
-    const long long ntile = (long long)ws.NS * (ws.NS + 1) / 2;
-    const long long blk = blockIdx.x / ntile;
-    const int tile = (int)(blockIdx.x % ntile);
-    int SI, SJ;
+    // the super-tiles of one block on ONE XCD (xcd_window_tile with blocks in the place of windows): they all read the
+    // block's 78 rows, and dealt round-robin over the 8 XCDs every L2 fetched them for itself (6.3 MB fetched per block
+    // at k = 1000 for 0.6 MB of rows)
+    long long blk;
+    int tile, SI, SJ;
+    if (!xcd_window_tile(ws.NS * (ws.NS + 1) / 2, A.hf_nblk, blk, tile)) return;
     pair_decode(tile, ws.NS, SI, SJ);
     const bool edge = !(64 * SJ + 63 < A.k);
     if (SI == SJ) {
@@ -457,6 +459,7 @@ __device__ __forceinline__ void gram64_wave_hfs_body(const tp_kargs_t& A, const 
     double* tv = lds;
     double* pI = lds + 128;
     double* pJ = lds + 192;
+    double* w0J = lds + 256;        // prior weights of the columns of SJ (0 beyond the last asset)
     const int lane = threadIdx.x;
     const int fr = lane & 15, fq = lane >> 4;
     const long long w = A.w_first + wl;
@@ -465,7 +468,7 @@ __device__ __forceinline__ void gram64_wave_hfs_body(const tp_kargs_t& A, const 
     const int mm = A.m;                                             // uniform intraday row count (host-checked)
     const int nr = A.n_rows ? A.n_rows[w] : A.n_r;
     const long long ntile = (long long)NS * (NS + 1) / 2;
-    long long co[NC];
+    int co[NC];
     double yb[NC], cs[NC];
     bool cval[NC], cbord[NC], cnone[NC];
 #pragma unroll
@@ -507,22 +510,18 @@ __device__ __forceinline__ void gram64_wave_hfs_body(const tp_kargs_t& A, const 
         const double sc = n0 * ((double)mm / ((double)mm - 1.0));
         const double minv = 1.0 / (double)mm;
         const double* w0 = A.w0 + w * k;
-        double tj[NB], w0j[NB], colp[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int gj = 64 * SJ + 16 * b + fr;
-            tj[b] = tv[64 + 16 * b + fr];
-            w0j[b] = (!EDGE || gj < k) ? w0[gj < k ? gj : k - 1] : 0.0;
-            colp[b] = 0.0;
+        double colp[NB];
+        {
+            const int gj = 64 * SJ + lane;
+            w0J[lane] = (!EDGE || gj < k) ? w0[gj < k ? gj : k - 1] : 0.0;
         }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) colp[b] = 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
         const d2* q = (const d2*)(hq + pair_index(SI, SJ, NS) * (SB * SB)) + lane;
         static_for_t<0, 4>([&](auto ac) __attribute__((always_inline)) {
             constexpr int a = decltype(ac)::value;
-            d2 v2[NB][2];
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) v2[b][h] = q[a * 512 + (b * 2 + h) * 64];
             double ti[4], w0i[4], rowp[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -531,19 +530,25 @@ __device__ __forceinline__ void gram64_wave_hfs_body(const tp_kargs_t& A, const 
                 w0i[r] = (gi < k) ? w0[gi] : 0.0;
                 rowp[r] = 0.0;
             }
+            d2 v2[NB][2];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) v2[b][h] = q[a * 512 + (b * 2 + h) * 64];
             static_for_t<0, NB>([&](auto bc) __attribute__((always_inline)) {
                 constexpr int b = decltype(bc)::value;
                 if constexpr (!DIAG || a <= b) {
                     d4 x = acc[NB * a + b];
                     x[0] += v2[b][0][0]; x[1] += v2[b][0][1];
                     x[2] += v2[b][1][0]; x[3] += v2[b][1][1];
+                    const double tjb = tv[64 + 16 * b + fr], w0jb = w0J[16 * b + fr];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int gi = 64 * SI + 16 * a + fq + 4 * r, gj = 64 * SJ + 16 * b + fr;
-                        double y = sc * fma(-minv * ti[r], tj[b], x[r]);
+                        double y = sc * fma(-minv * ti[r], tjb, x[r]);
                         y = (gi < k && gj < k) ? y : 0.0;
                         x[r] = y;
-                        rowp[r] = fma(y, w0j[b], rowp[r]);
+                        rowp[r] = fma(y, w0jb, rowp[r]);
                         if (!DIAG || a < b) colp[b] = fma(y, w0i[r], colp[b]);
                     }
                     acc[NB * a + b] = x;
@@ -624,7 +629,7 @@ __global__ void __launch_bounds__(64, 2) tiled_gram_wave_hfs_kernel(const tp_kar
     if (!xcd_window_tile(ws.NS * (ws.NS + 1) / 2, A.w_count, wl, tile)) return;
     pair_decode(tile, ws.NS, SI, SJ);
     const bool edge = !(64 * SJ + 63 < A.k);
-    __shared__ double lds[256];
+    __shared__ double lds[320];
     if (SI == SJ) {
         if (edge) gram64_wave_hfs_body<true, true>(A, ws, wl, SI, SJ, lds);
         else gram64_wave_hfs_body<true, false>(A, ws, wl, SI, SJ, lds);
